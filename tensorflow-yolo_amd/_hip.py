@@ -1,0 +1,114 @@
+"""ctypes binding of libyolo_hip.so (C ABI: include/yolo_hip.h).
+
+The HIP library IS the product path: there is no CPU fallback.  Loading fails loudly
+(ImportError with the build hint) when the shared object is missing.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
+
+ABI_VERSION = 1
+
+# enum yolo_op
+OP_INPUT, OP_CONV, OP_MAXPOOL, OP_ROUTE, OP_REORG, OP_SHORTCUT, OP_UPSAMPLE, OP_YOLO, OP_DETECTION = range(9)
+DTYPE_F32, DTYPE_F16 = 0, 1
+NMS_AGNOSTIC, NMS_PER_CLASS = 0, 1
+MAX_SRC, MAX_ANCHORS, MAX_SCALES = 4, 8, 4
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [("op", C.c_int32), ("n_src", C.c_int32), ("src", C.c_int32 * MAX_SRC),
+                ("filters", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32),
+                ("batch_norm", C.c_int32), ("leaky", C.c_int32),
+                ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32),
+                ("n_anchors", C.c_int32), ("anchors", C.c_double * (2 * MAX_ANCHORS))]
+
+
+class NetOptions(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("max_batch", C.c_int32), ("keep_all", C.c_int32),
+                ("cand_capacity", C.c_int32), ("max_boxes", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class Box(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("w", C.c_float), ("h", C.c_float),
+                ("prob", C.c_float), ("class_idx", C.c_int32)]
+
+
+class HeadDesc(C.Structure):
+    _fields_ = [("version", C.c_int32), ("n_classes", C.c_int32), ("n_scales", C.c_int32),
+                ("h", C.c_int32 * MAX_SCALES), ("w", C.c_int32 * MAX_SCALES), ("n_anchors", C.c_int32 * MAX_SCALES),
+                ("anchors", (C.c_double * (2 * MAX_ANCHORS)) * MAX_SCALES)]
+
+
+class KernelInfo(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("layer", C.c_int32), ("variant", C.c_int32), ("ksize", C.c_int32),
+                ("stride", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32),
+                ("flops", C.c_double), ("bytes", C.c_double), ("weight_bytes", C.c_double), ("name", C.c_char * 64)]
+
+
+# name -> (restype, argtypes); every symbol include/yolo_hip.h declares
+SIGNATURES = {
+    "yolo_hip_abi_version": (C.c_int, []),
+    "yolo_last_error": (C.c_char_p, []),
+    "yolo_net_create": (C.c_int, [C.POINTER(LayerDesc), C.c_int, C.POINTER(NetOptions), C.POINTER(C.c_void_p)]),
+    "yolo_net_destroy": (None, [C.c_void_p]),
+    "yolo_net_weight_count": (C.c_size_t, [C.c_void_p]),
+    "yolo_net_weights_bytes": (C.c_size_t, [C.c_void_p]),
+    "yolo_net_workspace_bytes": (C.c_size_t, [C.c_void_p]),
+    "yolo_net_output_count": (C.c_size_t, [C.c_void_p]),
+    "yolo_net_flops_per_image": (C.c_double, [C.c_void_p]),
+    "yolo_net_head_desc": (C.c_int, [C.c_void_p, C.POINTER(HeadDesc)]),
+    "yolo_net_set_head": (C.c_int, [C.c_void_p, C.POINTER(HeadDesc)]),
+    "yolo_net_num_kernels": (C.c_int, [C.c_void_p]),
+    "yolo_net_describe": (C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "yolo_net_load_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "yolo_net_bind_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "yolo_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "yolo_net_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "yolo_net_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(KernelInfo)]),
+    "yolo_net_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "yolo_net_read_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "yolo_decode_scratch_bytes": (C.c_size_t, [C.POINTER(HeadDesc), C.c_int, C.c_int]),
+    "yolo_decode_nms": (C.c_int, [C.POINTER(HeadDesc), C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int,
+                                  C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
+    "yolo_nms_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int,
+                                C.c_void_p, C.POINTER(C.c_int32)]),
+}
+
+_lib = None
+
+
+class YoloHipError(RuntimeError):
+    """A libyolo_hip call returned a non-zero status (message from yolo_last_error)."""
+
+
+def lib():
+    """Load (once) and return the shared library with typed entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libyolo_hip.so not found at %s: the HIP extension is the only compute path of this package "
+            "(no CPU fallback). Build it with `python __graft_entry__.py` or `make -C tensorflow-yolo_amd/csrc`."
+            % LIB_PATH)
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)      # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    v = handle.yolo_hip_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError("libyolo_hip.so ABI version %d, binding expects %d: rebuild the library" % (v, ABI_VERSION))
+    _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().yolo_last_error()
+        raise YoloHipError("%s failed (status %d): %s" % (what or "libyolo_hip call", rc, (msg or b"").decode()))

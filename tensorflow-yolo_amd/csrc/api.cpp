@@ -1,0 +1,454 @@
+// C ABI of libyolo_hip.so (declared in include/yolo_hip.h).  No exceptions cross the boundary.
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "yolo_internal.h"
+
+namespace yolo {
+const char *get_error();
+}
+using namespace yolo;
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+            return YOLO_ERR_HIP;                                                               \
+        }                                                                                      \
+    } while (0)
+
+static int fail(int code, const std::string &msg) {
+    set_error(msg);
+    return code;
+}
+
+extern "C" {
+
+int yolo_hip_abi_version(void) { return YOLO_HIP_ABI_VERSION; }
+const char *yolo_last_error(void) { return get_error(); }
+
+int yolo_net_create(const yolo_layer_desc *layers, int n_layers, const yolo_net_options *opt, yolo_net **out) {
+    if (!layers || !opt || !out || n_layers <= 0) return fail(YOLO_ERR_ARG, "yolo_net_create: null argument");
+    if (opt->dtype != YOLO_DTYPE_F16 && opt->dtype != YOLO_DTYPE_F32) return fail(YOLO_ERR_ARG, "yolo_net_create: bad dtype");
+    if (opt->max_batch <= 0) return fail(YOLO_ERR_ARG, "yolo_net_create: max_batch must be positive");
+    yolo_net *net = new (std::nothrow) yolo_net();
+    if (!net) return fail(YOLO_ERR_ARG, "out of host memory");
+    net->opt = *opt;
+    if (net->opt.cand_capacity <= 0) net->opt.cand_capacity = 4096;
+    if (net->opt.max_boxes <= 0) net->opt.max_boxes = 256;
+    if (nms_lds_bytes(net->opt.cand_capacity) > 160 * 1024) {
+        delete net;
+        return fail(YOLO_ERR_ARG, "cand_capacity too large for the 160 KiB LDS sort (max 4096)");
+    }
+    std::string err;
+    int rc = YOLO_ERR_PLAN;
+    try {
+        rc = plan_network(net, layers, n_layers, err);
+    } catch (const std::exception &e) {
+        err = e.what();
+    }
+    if (rc != YOLO_OK) {
+        delete net;
+        return fail(rc, "yolo_net_create: " + err);
+    }
+    *out = net;
+    return YOLO_OK;
+}
+
+void yolo_net_destroy(yolo_net *net) { delete net; }
+
+size_t yolo_net_weight_count(const yolo_net *net) { return net ? net->weight_count : 0; }
+size_t yolo_net_weights_bytes(const yolo_net *net) { return net ? net->weights_bytes : 0; }
+size_t yolo_net_workspace_bytes(const yolo_net *net) { return net ? net->workspace_bytes : 0; }
+size_t yolo_net_output_count(const yolo_net *net) { return net ? net->out_count : 0; }
+double yolo_net_flops_per_image(const yolo_net *net) { return net ? net->flops_per_image : 0.0; }
+int yolo_net_num_kernels(const yolo_net *net) { return net ? (int)net->kernels.size() : 0; }
+
+int yolo_net_head_desc(const yolo_net *net, yolo_head_desc *out) {
+    if (!net || !out) return fail(YOLO_ERR_ARG, "yolo_net_head_desc: null argument");
+    *out = net->head;
+    return YOLO_OK;
+}
+
+static int check_head(const yolo_head_desc *h, size_t out_count, std::string &err) {
+    if (h->version != 2 && h->version != 3) { err = "head version must be 2 or 3"; return YOLO_ERR_ARG; }
+    if (h->n_scales < 1 || h->n_scales > YOLO_MAX_SCALES || h->n_classes < 1) { err = "bad head geometry"; return YOLO_ERR_ARG; }
+    size_t rows = 0;
+    for (int s = 0; s < h->n_scales; ++s) {
+        if (h->n_anchors[s] < 1 || h->n_anchors[s] > YOLO_MAX_ANCHORS || h->h[s] < 1 || h->w[s] < 1) { err = "bad head scale"; return YOLO_ERR_ARG; }
+        rows += (size_t)h->h[s] * h->w[s] * h->n_anchors[s];
+    }
+    if (out_count && rows * (5 + h->n_classes) != out_count) { err = "head geometry does not match the network output size"; return YOLO_ERR_ARG; }
+    return YOLO_OK;
+}
+
+int yolo_net_set_head(yolo_net *net, const yolo_head_desc *head) {
+    if (!net || !head) return fail(YOLO_ERR_ARG, "yolo_net_set_head: null argument");
+    std::string err;
+    int rc = check_head(head, net->out_count, err);
+    if (rc) return fail(rc, "yolo_net_set_head: " + err);
+    net->head = *head;
+    return YOLO_OK;
+}
+
+size_t yolo_net_describe(const yolo_net *net, char *buf, size_t cap) {
+    if (!net) return 0;
+    std::string s = describe(net);
+    if (buf && cap) {
+        size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
+        memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return s.size() + 1;
+}
+
+int yolo_net_load_weights(yolo_net *net, const float *host_weights, size_t n, void *dev_weights, size_t dev_bytes) {
+    if (!net || !dev_weights || (!host_weights && n)) return fail(YOLO_ERR_ARG, "yolo_net_load_weights: null argument");
+    if (dev_bytes < net->weights_bytes) return fail(YOLO_ERR_ARG, "yolo_net_load_weights: device buffer too small");
+    if ((uintptr_t)dev_weights % 256) return fail(YOLO_ERR_ARG, "yolo_net_load_weights: device buffer must be 256-byte aligned");
+    std::vector<unsigned char> blob;
+    std::string err;
+    int rc = pack_weights(net, host_weights, n, blob, err);
+    if (rc) return fail(rc, "yolo_net_load_weights: " + err);
+    HIP_TRY(hipMemcpy(dev_weights, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    net->dev_weights = static_cast<unsigned char *>(dev_weights);
+    net->weights_loaded = true;
+    return YOLO_OK;
+}
+
+int yolo_net_bind_workspace(yolo_net *net, void *ws, size_t bytes) {
+    if (!net || !ws) return fail(YOLO_ERR_ARG, "yolo_net_bind_workspace: null argument");
+    if (bytes < net->workspace_bytes) return fail(YOLO_ERR_ARG, "yolo_net_bind_workspace: workspace too small");
+    if ((uintptr_t)ws % 256) return fail(YOLO_ERR_ARG, "yolo_net_bind_workspace: workspace must be 256-byte aligned");
+    net->dev_ws = static_cast<unsigned char *>(ws);
+    net->dev_ws_bytes = bytes;
+    return YOLO_OK;
+}
+
+}  // extern "C"
+
+// ---- forward ------------------------------------------------------------------------------------
+namespace {
+
+struct Ptrs {
+    yolo_net *net;
+    const float *in;
+    float *out;
+    unsigned char *buf_base(int b) const {
+        if (b == BUF_USER_IN) return reinterpret_cast<unsigned char *>(const_cast<float *>(in));
+        if (b == BUF_USER_OUT) return reinterpret_cast<unsigned char *>(out);
+        return net->dev_ws + net->buffers[b].offset;
+    }
+    int esz(const View &v) const { return v.f32 ? 4 : net->esize; }
+    // element pointer of channel 0 of pixel 0 of image 0 of the view
+    unsigned char *view_ptr(const View &v) const { return buf_base(v.buf) + (size_t)(v.base + v.coff) * esz(v); }
+};
+
+int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, hipStream_t s, hipEvent_t *ev = nullptr) {
+    Ptrs P{net, in_dev, out_dev};
+    const int dtype = net->opt.dtype;
+    const int epc = net->epc;
+    for (size_t ki = 0; ki < net->kernels.size(); ++ki) {
+        const Kernel &k = net->kernels[ki];
+        hipError_t e = hipSuccess;
+        if (ev && hipEventRecord(ev[2 * ki], s) != hipSuccess) return fail(YOLO_ERR_HIP, "hipEventRecord failed");
+        switch (k.kind) {
+        case K_PREP: {
+            PrepParams p;
+            p.in = in_dev;
+            p.out = P.view_ptr(k.out);
+            p.pixels = (long long)batch * k.in.H * k.in.W;
+            p.C = k.in.C;
+            p.Cpad = k.out.ld;
+            e = launch_prep(p, dtype, s);
+            break;
+        }
+        case K_CONV: {
+            ConvParams p;
+            memset(&p, 0, sizeof p);
+            const View &in = k.in;
+            const long long in_bytes = (long long)batch * in.img_stride * net->esize;
+            if (in_bytes > 0x7ffffff0LL)
+                return fail(YOLO_ERR_ARG, "conv input tensor exceeds 2 GiB (32-bit buffer addressing): lower the batch");
+            p.in = P.buf_base(in.buf);
+            p.in_bytes = (uint32_t)in_bytes;
+            p.wgt = net->dev_weights + k.w_off;
+            p.wgt_bytes = (uint32_t)k.w_bytes;
+            p.bias = reinterpret_cast<const float *>(net->dev_weights + k.b_off);
+            p.H = in.H; p.W = in.W; p.in_ld = in.ld; p.in_coff = in.coff; p.in_img_stride = in.img_stride;
+            const yolo_layer_desc &d = net->layers[k.src_layer].d;
+            const int Ho = net->layers[k.src_layer].H, Wo = net->layers[k.src_layer].W;
+            p.Ho = Ho; p.Wo = Wo; p.HoWo = Ho * Wo;
+            const long long M = (long long)batch * Ho * Wo;
+            if (M > 0x7fffffffLL) return fail(YOLO_ERR_ARG, "too many output pixels for one launch");
+            p.M = (int)M;
+            p.Cout = k.cout;
+            p.out = P.view_ptr(k.out);
+            p.out_ld = k.out.ld;
+            p.out_img_stride = k.out.img_stride;
+            p.out_f32 = k.out.f32 || dtype == YOLO_DTYPE_F32;
+            p.ksize = d.ksize; p.stride = d.stride; p.pad = (d.ksize - 1) / 2; p.taps = d.ksize * d.ksize;
+            p.ktiles = k.ktiles;
+            p.tiles_per_tap = k.perchunk ? 1 : k.cpt / 8;
+            p.cpt_shift = k.cpt == 1 ? 0 : k.cpt == 2 ? 1 : 2;
+            p.wrow_bytes = (uint32_t)k.ktiles * 128;
+            p.leaky = k.leaky; p.outmode = k.outmode; p.has_res = k.has_res;
+            const int ch = k.cfg == CFG_N32 ? 8 : 16;
+            const int oepc = p.out_f32 ? 4 : epc;
+            p.vec_out = (k.cout % ch == 0) && (k.out.ld % oepc == 0) && ((k.out.base + k.out.coff) % oepc == 0) &&
+                        (k.out.img_stride % oepc == 0) && ((uintptr_t)P.buf_base(k.out.buf) % 16 == 0);
+            if (k.has_res) {
+                p.res = P.view_ptr(k.in2);
+                p.res_ld = k.in2.ld;
+                p.res_img_stride = k.in2.img_stride;
+                p.vec_res = (k.cout % ch == 0) && (k.in2.ld % epc == 0) && (k.in2.coff % epc == 0) && (k.in2.img_stride % epc == 0);
+            }
+            e = launch_conv(p, dtype, k.cfg, k.perchunk != 0, s);
+            break;
+        }
+        case K_POOL: {
+            PoolParams p;
+            p.in = P.view_ptr(k.in);
+            p.out = P.view_ptr(k.out);
+            p.H = k.in.H; p.W = k.in.W; p.C = k.in.C; p.in_ld = k.in.ld;
+            p.Ho = k.out.H; p.Wo = k.out.W; p.out_ld = k.out.ld; p.stride = k.pool_stride;
+            p.in_img_stride = k.in.img_stride; p.out_img_stride = k.out.img_stride;
+            p.total = (long long)batch * k.out.H * k.out.W;
+            e = launch_pool(p, dtype, s);
+            break;
+        }
+        case K_ELTWISE: {
+            EltParams p;
+            memset(&p, 0, sizeof p);
+            p.a = P.view_ptr(k.in);
+            p.a_f32 = k.in.f32;
+            p.b = k.has_res ? P.view_ptr(k.in2) : nullptr;
+            p.out = P.view_ptr(k.out);
+            p.H = k.in.H; p.W = k.in.W; p.C = k.in.C;
+            p.a_ld = k.in.ld; p.b_ld = k.in2.ld; p.out_ld = k.out.ld;
+            p.outmode = k.outmode;
+            p.out_f32 = k.out.f32 || dtype == YOLO_DTYPE_F32;
+            p.a_img_stride = k.in.img_stride; p.b_img_stride = k.in2.img_stride; p.out_img_stride = k.out.img_stride;
+            p.total = (long long)batch * k.in.H * k.in.W * k.in.C;
+            e = launch_eltwise(p, dtype, s);
+            break;
+        }
+        }
+        if (e != hipSuccess) {
+            char msg[160];
+            snprintf(msg, sizeof msg, "kernel %zu (layer %d) launch failed: %s", ki, k.layer, hipGetErrorString(e));
+            return fail(YOLO_ERR_HIP, msg);
+        }
+        if (ev && hipEventRecord(ev[2 * ki + 1], s) != hipSuccess) return fail(YOLO_ERR_HIP, "hipEventRecord failed");
+    }
+    return YOLO_OK;
+}
+
+int check_ready(yolo_net *net, const void *in, int batch, const char *who) {
+    if (!net || !in) return fail(YOLO_ERR_ARG, std::string(who) + ": null argument");
+    if (batch <= 0 || batch > net->opt.max_batch) return fail(YOLO_ERR_ARG, std::string(who) + ": batch outside 1..max_batch");
+    if (!net->weights_loaded && net->weight_count) return fail(YOLO_ERR_STATE, std::string(who) + ": weights not loaded");
+    if (!net->dev_ws) return fail(YOLO_ERR_STATE, std::string(who) + ": workspace not bound");
+    return YOLO_OK;
+}
+
+void fill_decode(const yolo_head_desc &h, DecodeParams &dp) {
+    dp.version = h.version;
+    dp.n_classes = h.n_classes;
+    dp.n_scales = h.n_scales;
+    int row0 = 0;
+    for (int s = 0; s < h.n_scales; ++s) {
+        dp.sc[s].row0 = row0; dp.sc[s].h = h.h[s]; dp.sc[s].w = h.w[s]; dp.sc[s].na = h.n_anchors[s];
+        for (int a = 0; a < h.n_anchors[s]; ++a) { dp.sc[s].aw[a] = h.anchors[s][2 * a]; dp.sc[s].ah[a] = h.anchors[s][2 * a + 1]; }
+        row0 += h.h[s] * h.w[s] * h.n_anchors[s];
+    }
+    dp.rows = row0;
+}
+
+int run_decode_nms(const yolo_head_desc &h, const float *logits, int batch, double thr, double iou, int mode, int cap,
+                   int max_boxes, unsigned char *cand, int *cand_count, yolo_box *boxes, int32_t *counts, int32_t *status,
+                   int32_t *keep_idx, hipStream_t s) {
+    DecodeParams dp;
+    memset(&dp, 0, sizeof dp);
+    fill_decode(h, dp);
+    dp.logits = logits;
+    dp.threshold = (float)thr;      // `p < threshold` compares in float32 under NumPy 2 (weak Python float)
+    dp.cap = cap;
+    dp.cand = cand;
+    dp.cand_count = cand_count;
+    dp.total_rows = (long long)batch * dp.rows;
+    HIP_TRY(launch_decode(dp, batch, s));
+    NmsParams np;
+    np.cand = reinterpret_cast<const Candidate *>(cand);
+    np.cand_count = cand_count;
+    np.cap = cap; np.max_boxes = max_boxes; np.mode = mode;
+    np.iou_threshold = iou;
+    np.boxes = boxes; np.counts = counts; np.status = status; np.keep_idx = keep_idx;
+    HIP_TRY(launch_nms(np, batch, s));
+    return YOLO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int yolo_net_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, void *stream) {
+    int rc = check_ready(net, in_dev, batch, "yolo_net_forward");
+    if (rc) return rc;
+    if (!out_dev) return fail(YOLO_ERR_ARG, "yolo_net_forward: null output");
+    return run_forward(net, in_dev, batch, out_dev, static_cast<hipStream_t>(stream));
+}
+
+int yolo_net_forward_timed(yolo_net *net, const float *in_dev, int batch, float *out_dev, void *stream, float *ms_host) {
+    int rc = check_ready(net, in_dev, batch, "yolo_net_forward_timed");
+    if (rc) return rc;
+    if (!out_dev || !ms_host) return fail(YOLO_ERR_ARG, "yolo_net_forward_timed: null output");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nk = net->kernels.size();
+    std::vector<hipEvent_t> ev(2 * nk, nullptr);
+    for (auto &e : ev)
+        if (hipEventCreate(&e) != hipSuccess) return fail(YOLO_ERR_HIP, "hipEventCreate failed");
+    rc = run_forward(net, in_dev, batch, out_dev, s, ev.data());
+    if (rc == YOLO_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(YOLO_ERR_HIP, "hipStreamSynchronize failed");
+    for (size_t k = 0; rc == YOLO_OK && k < nk; ++k)
+        if (hipEventElapsedTime(&ms_host[k], ev[2 * k], ev[2 * k + 1]) != hipSuccess) rc = fail(YOLO_ERR_HIP, "hipEventElapsedTime failed");
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out) {
+    if (!net || !out || kernel < 0 || kernel >= (int)net->kernels.size()) return fail(YOLO_ERR_ARG, "yolo_net_kernel_info: bad argument");
+    const Kernel &k = net->kernels[kernel];
+    memset(out, 0, sizeof *out);
+    out->kind = k.kind; out->layer = k.layer;
+    const char *t = net->opt.dtype == YOLO_DTYPE_F16 ? "f16" : "f32";
+    auto elems = [](const View &v) { return (double)v.H * v.W * v.C; };
+    auto esz = [&](const View &v) { return v.f32 ? 4.0 : (double)net->esize; };
+    if (k.kind == K_CONV) {
+        const LayerInfo &li = net->layers[k.src_layer];
+        out->variant = k.cfg + 4 * k.perchunk;
+        out->ksize = k.ksize; out->stride = k.stride; out->cin = k.cin; out->cout = k.cout; out->out_h = li.H; out->out_w = li.W;
+        out->flops = 2.0 * li.H * li.W * k.cout * k.ksize * k.ksize * k.cin;
+        out->bytes = (double)k.in.H * k.in.W * k.cin * net->esize + elems(k.out) * esz(k.out) + (k.has_res ? elems(k.in2) * net->esize : 0.0);
+        out->weight_bytes = (double)k.cout * k.ksize * k.ksize * k.cin * net->esize + 4.0 * k.cout;
+        snprintf(out->name, sizeof out->name, "conv_igemm<%s,N%d,%s>", t, k.cfg == CFG_N128 ? 128 : k.cfg == CFG_N64 ? 64 : 32,
+                 k.perchunk ? "perchunk" : "uniform");
+    } else {
+        out->out_h = k.out.H; out->out_w = k.out.W; out->cout = k.out.C; out->cin = k.in.C;
+        out->bytes = elems(k.in) * (k.in.f32 ? 4.0 : net->esize) + elems(k.out) * esz(k.out) + (k.has_res ? elems(k.in2) * net->esize : 0.0);
+        snprintf(out->name, sizeof out->name, "%s<%s>", k.kind == K_PREP ? "prep" : k.kind == K_POOL ? "pool" : "eltwise", t);
+    }
+    return YOLO_OK;
+}
+
+int yolo_net_detect(yolo_net *net, const float *in_dev, int batch, double threshold, double iou_threshold, int nms_mode,
+                    yolo_box *boxes_dev, int32_t *counts_dev, int32_t *status_dev, void *stream) {
+    int rc = check_ready(net, in_dev, batch, "yolo_net_detect");
+    if (rc) return rc;
+    if (!boxes_dev || !counts_dev || !status_dev) return fail(YOLO_ERR_ARG, "yolo_net_detect: null output");
+    std::string err;
+    rc = check_head(&net->head, net->out_count, err);
+    if (rc) return fail(YOLO_ERR_STATE, "yolo_net_detect: head geometry not set (" + err + "); call yolo_net_set_head");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float *logits = reinterpret_cast<float *>(net->dev_ws + net->logits_off);
+    rc = run_forward(net, in_dev, batch, logits, s);
+    if (rc) return rc;
+    return run_decode_nms(net->head, logits, batch, threshold, iou_threshold, nms_mode, net->opt.cand_capacity,
+                          net->opt.max_boxes, net->dev_ws + net->cand_off, reinterpret_cast<int *>(net->dev_ws + net->count_off),
+                          boxes_dev, counts_dev, status_dev, nullptr, s);
+}
+
+int yolo_net_read_layer(yolo_net *net, int layer, int batch, float *host_out, size_t n) {
+    if (!net || !host_out) return fail(YOLO_ERR_ARG, "yolo_net_read_layer: null argument");
+    if (!net->opt.keep_all) return fail(YOLO_ERR_STATE, "yolo_net_read_layer: create the net with keep_all=1");
+    if (layer < 0 || layer >= (int)net->layers.size() || !net->layers[layer].materialised)
+        return fail(YOLO_ERR_ARG, "yolo_net_read_layer: layer has no materialised tensor (fused away or out of range)");
+    const View &v = net->layers[layer].view;
+    if (v.buf < 0) return fail(YOLO_ERR_ARG, "yolo_net_read_layer: layer lives in a caller-owned tensor");
+    const size_t need = (size_t)batch * v.H * v.W * v.C;
+    if (n < need || batch > net->opt.max_batch) return fail(YOLO_ERR_ARG, "yolo_net_read_layer: host buffer too small");
+    HIP_TRY(hipDeviceSynchronize());
+    const Buffer &b = net->buffers[v.buf];
+    const int es = v.f32 ? 4 : net->esize;
+    std::vector<unsigned char> tmp((size_t)batch * v.img_stride * es);
+    HIP_TRY(hipMemcpy(tmp.data(), net->dev_ws + b.offset, tmp.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < batch; ++i)
+        for (long long px = 0; px < (long long)v.H * v.W; ++px)
+            for (int c = 0; c < v.C; ++c) {
+                const size_t e = (size_t)i * v.img_stride + (size_t)px * v.ld + v.coff + c;
+                float f;
+                if (es == 4) f = reinterpret_cast<const float *>(tmp.data())[e];
+                else f = (float)reinterpret_cast<const _Float16 *>(tmp.data())[e];
+                host_out[((size_t)i * v.H * v.W + px) * v.C + c] = f;
+            }
+    return YOLO_OK;
+}
+
+size_t yolo_decode_scratch_bytes(const yolo_head_desc *head, int batch, int cand_capacity) {
+    (void)head;
+    if (batch <= 0) return 0;
+    if (cand_capacity <= 0) cand_capacity = 4096;
+    return ((sizeof(Candidate) * (size_t)cand_capacity * batch + 255) & ~(size_t)255) + ((sizeof(int) * (size_t)batch + 255) & ~(size_t)255);
+}
+
+int yolo_decode_nms(const yolo_head_desc *head, const float *logits_dev, int batch, double threshold, double iou_threshold,
+                    int nms_mode, int cand_capacity, int max_boxes, void *scratch_dev, size_t scratch_bytes, yolo_box *boxes_dev,
+                    int32_t *counts_dev, int32_t *status_dev, void *stream) {
+    if (!head || !logits_dev || !scratch_dev || !boxes_dev || !counts_dev || !status_dev || batch <= 0)
+        return fail(YOLO_ERR_ARG, "yolo_decode_nms: null argument");
+    if (cand_capacity <= 0) cand_capacity = 4096;
+    if (max_boxes <= 0) max_boxes = 256;
+    std::string err;
+    int rc = check_head(head, 0, err);
+    if (rc) return fail(rc, "yolo_decode_nms: " + err);
+    if (nms_lds_bytes(cand_capacity) > 160 * 1024) return fail(YOLO_ERR_ARG, "yolo_decode_nms: cand_capacity above 4096");
+    if (scratch_bytes < yolo_decode_scratch_bytes(head, batch, cand_capacity)) return fail(YOLO_ERR_ARG, "yolo_decode_nms: scratch too small");
+    unsigned char *cand = static_cast<unsigned char *>(scratch_dev);
+    int *cnt = reinterpret_cast<int *>(cand + ((sizeof(Candidate) * (size_t)cand_capacity * batch + 255) & ~(size_t)255));
+    return run_decode_nms(*head, logits_dev, batch, threshold, iou_threshold, nms_mode, cand_capacity, max_boxes, cand, cnt,
+                          boxes_dev, counts_dev, status_dev, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int yolo_nms_host(const double *xywh, const float *prob, const int32_t *class_idx, int n, double iou_threshold, int nms_mode,
+                  int32_t *keep_idx, int32_t *n_keep) {
+    if (n < 0 || !n_keep || (n && (!xywh || !prob || !class_idx || !keep_idx))) return fail(YOLO_ERR_ARG, "yolo_nms_host: null argument");
+    *n_keep = 0;
+    if (n == 0) return YOLO_OK;                      // base.py:196-197
+    if (n > 4096) return fail(YOLO_ERR_OVERFLOW, "yolo_nms_host: more than 4096 boxes");
+    std::vector<Candidate> c(n);
+    for (int i = 0; i < n; ++i) {
+        c[i].x = (float)xywh[4 * i]; c[i].y = (float)xywh[4 * i + 1]; c[i].w = xywh[4 * i + 2]; c[i].h = xywh[4 * i + 3];
+        c[i].prob = prob[i]; c[i].cls = class_idx[i]; c[i].scan = (unsigned)i; c[i].pad_ = 0;
+    }
+    unsigned char *dev = nullptr;
+    const size_t cb = sizeof(Candidate) * (size_t)n, bb = sizeof(yolo_box) * (size_t)n, ib = sizeof(int) * (size_t)n;
+    const size_t total = ((cb + 255) & ~(size_t)255) + ((bb + 255) & ~(size_t)255) + ((ib + 255) & ~(size_t)255) + 768;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dev), total));
+    unsigned char *d_c = dev, *d_b = d_c + ((cb + 255) & ~(size_t)255), *d_i = d_b + ((bb + 255) & ~(size_t)255);
+    int *d_cnt = reinterpret_cast<int *>(d_i + ((ib + 255) & ~(size_t)255));    // [count, kept, status] 256 B apart
+    int rc = YOLO_OK;
+    do {
+        if (hipMemcpy(d_c, c.data(), cb, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_cnt, &n, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(YOLO_ERR_HIP, "yolo_nms_host: H2D copy failed"); break; }
+        NmsParams np;
+        np.cand = reinterpret_cast<const Candidate *>(d_c);
+        np.cand_count = d_cnt;
+        np.cap = n; np.max_boxes = n; np.mode = nms_mode; np.iou_threshold = iou_threshold;
+        np.boxes = reinterpret_cast<yolo_box *>(d_b);
+        np.counts = d_cnt + 64; np.status = d_cnt + 128;
+        np.keep_idx = reinterpret_cast<int *>(d_i);
+        hipError_t e = launch_nms(np, 1, nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { rc = fail(YOLO_ERR_HIP, std::string("yolo_nms_host: ") + hipGetErrorString(e)); break; }
+        int kept = 0;
+        if (hipMemcpy(&kept, d_cnt + 64, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(keep_idx, d_i, sizeof(int) * (size_t)kept, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(YOLO_ERR_HIP, "yolo_nms_host: D2H copy failed"); break; }
+        *n_keep = kept;
+    } while (0);
+    hipFree(dev);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+// Bandwidth kernels around the conv stack: input cast/pad, max-pool, and the generic strided
+// element-wise fallback (standalone shortcut / upsample / reorg / concat-copy / f32 convert) the
+// planner uses when a fusion into a conv epilogue is not possible.
+#include "yolo_internal.h"
+
+namespace yolo {
+
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+
+// feed point of the graph (net/layers.py:106-109): float32 NHWC -> T NHWC with the channel count
+// padded to one 16-byte chunk (zeros), so the first conv can run the chunked implicit GEMM.
+template <typename T>
+__global__ void __launch_bounds__(256) prep_kernel(const PrepParams p) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long px = (long long)blockIdx.x * blockDim.x + threadIdx.x; px < p.pixels; px += stride) {
+        const float *src = p.in + px * p.C;
+        T *dst = reinterpret_cast<T *>(p.out) + px * p.Cpad;
+        for (int c0 = 0; c0 < p.Cpad; c0 += 16 / (int)sizeof(T)) {
+            T t[16 / sizeof(T)];
+#pragma unroll
+            for (int e = 0; e < 16 / (int)sizeof(T); ++e) t[e] = (c0 + e < p.C) ? (T)src[c0 + e] : (T)0.f;
+            uint4v u;
+            __builtin_memcpy(&u, t, 16);
+            *reinterpret_cast<uint4v *>(dst + c0) = u;
+        }
+    }
+}
+
+// net/layers.py:70-81.  stride 2: zero pad (0 before, 1 after) then 2x2 VALID -- the pad row/col is
+// only read for odd H/W and then takes part in the max as 0.  stride 1: TF SAME, window clipped.
+template <typename T, bool VEC>
+__global__ void __launch_bounds__(256) pool_kernel(const PoolParams p) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int STEP = VEC ? EPC : 1;
+    const int cchunks = (p.C + STEP - 1) / STEP;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < p.total; w += stride) {
+        const int cc = (int)(w % cchunks);
+        long long t = w / cchunks;
+        const int ox = (int)(t % p.Wo); t /= p.Wo;
+        const int oy = (int)(t % p.Ho);
+        const long long n = t / p.Ho;
+        const int iy = oy * p.stride, ix = ox * p.stride;
+        float best[STEP];
+#pragma unroll
+        for (int e = 0; e < STEP; ++e) best[e] = -INFINITY;
+        const T *base = reinterpret_cast<const T *>(p.in) + n * p.in_img_stride + cc * STEP;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int y = iy + dy, x = ix + dx;
+                if (y < p.H && x < p.W) {
+                    const T *q = base + ((long long)y * p.W + x) * p.in_ld;
+                    if (VEC) {
+                        const uint4v u = *reinterpret_cast<const uint4v *>(q);
+                        T tv[EPC];
+                        __builtin_memcpy(tv, &u, 16);
+#pragma unroll
+                        for (int e = 0; e < STEP; ++e) best[e] = fmaxf(best[e], (float)tv[e]);
+                    } else {
+                        best[0] = fmaxf(best[0], (float)q[0]);
+                    }
+                } else if (p.stride == 2) {     // explicit zero padding takes part (layers.py:72-73)
+#pragma unroll
+                    for (int e = 0; e < STEP; ++e) best[e] = fmaxf(best[e], 0.f);
+                }
+            }
+        T *o = reinterpret_cast<T *>(p.out) + n * p.out_img_stride + ((long long)oy * p.Wo + ox) * p.out_ld + cc * STEP;
+        if (VEC) {
+            T tv[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) tv[e] = (T)best[e];
+            uint4v u;
+            __builtin_memcpy(&u, tv, 16);
+            *reinterpret_cast<uint4v *>(o) = u;
+        } else {
+            o[0] = (T)best[0];
+        }
+    }
+}
+
+// Generic fallback, one element per thread: out[map(n,y,x)][c] = a[n,y,x,c] (+ b[n,y,x,c]).
+// map: identity, nearest upsample x2 (layers.py:112-116) or block-major reorg x2 (layers.py:90-97).
+template <typename T>
+__global__ void __launch_bounds__(256) eltwise_kernel(const EltParams p) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < p.total; w += stride) {
+        const int c = (int)(w % p.C);
+        long long t = w / p.C;
+        const int x = (int)(t % p.W); t /= p.W;
+        const int y = (int)(t % p.H);
+        const long long n = t / p.H;
+        const long long pa = n * p.a_img_stride + ((long long)y * p.W + x) * p.a_ld + c;
+        float v = p.a_f32 ? reinterpret_cast<const float *>(p.a)[pa] : (float)reinterpret_cast<const T *>(p.a)[pa];
+        if (p.b) {
+            const float r = (float)reinterpret_cast<const T *>(p.b)[n * p.b_img_stride + ((long long)y * p.W + x) * p.b_ld + c];
+            // the reference adds two tensors of type T: round the sum once in T
+            v = v + r;
+        }
+        long long off[4];
+        int npos = 1;
+        if (p.outmode == OUT_NORMAL) {
+            off[0] = n * p.out_img_stride + ((long long)y * p.W + x) * p.out_ld + c;
+        } else if (p.outmode == OUT_UP2) {
+            const long long W2 = 2LL * p.W;
+            const long long b0 = n * p.out_img_stride + ((2LL * y) * W2 + 2LL * x) * p.out_ld + c;
+            off[0] = b0; off[1] = b0 + p.out_ld; off[2] = b0 + W2 * p.out_ld; off[3] = b0 + (W2 + 1) * p.out_ld;
+            npos = 4;
+        } else {
+            const int W2 = p.W >> 1;
+            off[0] = n * p.out_img_stride + ((long long)(y >> 1) * W2 + (x >> 1)) * p.out_ld + ((y & 1) * 2 + (x & 1)) * p.C + c;
+        }
+        for (int q = 0; q < npos; ++q) {
+            if (p.out_f32) reinterpret_cast<float *>(p.out)[off[q]] = v;
+            else reinterpret_cast<T *>(p.out)[off[q]] = (T)v;
+        }
+    }
+}
+
+static inline unsigned grid_for(long long work) {
+    long long g = (work + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;     // 16 blocks per CU, grid-stride the rest
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+hipError_t launch_prep(const PrepParams &p, int dtype, hipStream_t s) {
+    if (dtype == YOLO_DTYPE_F16) hipLaunchKernelGGL(prep_kernel<_Float16>, dim3(grid_for(p.pixels)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(prep_kernel<float>, dim3(grid_for(p.pixels)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_pool(const PoolParams &p0, int dtype, hipStream_t s) {
+    PoolParams p = p0;
+    const int epc = dtype == YOLO_DTYPE_F16 ? 8 : 4;
+    const bool vec = (p.C % epc == 0) && (p.in_ld % epc == 0) && (p.out_ld % epc == 0) &&
+                     ((uintptr_t)p.in % 16 == 0) && ((uintptr_t)p.out % 16 == 0) &&
+                     (p.in_img_stride % epc == 0) && (p.out_img_stride % epc == 0);
+    const long long pix = p.total;      // caller passes B*Ho*Wo
+    p.total = pix * (vec ? p.C / epc : p.C);
+    const dim3 g(grid_for(p.total)), b(256);
+    if (dtype == YOLO_DTYPE_F16) {
+        if (vec) hipLaunchKernelGGL((pool_kernel<_Float16, true>), g, b, 0, s, p);
+        else hipLaunchKernelGGL((pool_kernel<_Float16, false>), g, b, 0, s, p);
+    } else {
+        if (vec) hipLaunchKernelGGL((pool_kernel<float, true>), g, b, 0, s, p);
+        else hipLaunchKernelGGL((pool_kernel<float, false>), g, b, 0, s, p);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_eltwise(const EltParams &p, int dtype, hipStream_t s) {
+    const dim3 g(grid_for(p.total)), b(256);
+    if (dtype == YOLO_DTYPE_F16) hipLaunchKernelGGL(eltwise_kernel<_Float16>, g, b, 0, s, p);
+    else hipLaunchKernelGGL(eltwise_kernel<float>, g, b, 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace yolo

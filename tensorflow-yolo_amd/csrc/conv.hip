@@ -1,0 +1,313 @@
+// Fused conv2d + folded-BN bias + leaky ReLU [+ residual] [+ upsample / reorg / concat-slice write]
+// as an implicit GEMM on the gfx950 matrix cores.  Replaces tf.layers.conv2d +
+// tf.layers.batch_normalization + tf.nn.leaky_relu (net/layers.py:17-67), and absorbs
+// shortcut (:100-103), route (:84-87), upsample (:112-116) and reorg (:90-97).
+//
+// GEMM view:  D[cout][pixel] = sum_k  Wt[cout][k] * X[pixel][k],   k = (kh, kw, cin)
+//   * the WEIGHT tile is the MFMA A operand and the PIXEL tile the B operand, so that in the
+//     16x16 accumulator a lane owns 4 consecutive couts of ONE pixel; with the cout<->LDS-row
+//     permutation below a lane ends up with 4*TM contiguous channels of a pixel and the
+//     epilogue writes 16/32-byte NHWC vectors (four lanes = one 64/128-byte line).
+//   * K runs in 16-byte chunks (8 halfs / 4 floats).  A K tile is 8 chunks = one 128-byte LDS
+//     row per cout / pixel.  "uniform" mode: Cin is a multiple of 8 chunks, the tap (kh,kw) is
+//     the same for the whole tile.  "perchunk" mode (Cin = 1, 2 or 4 chunks: first layer and the
+//     narrow early layers): every chunk of the tile carries its own tap.
+//   * im2col is never materialised: each thread keeps, per pixel row it stages, a 32-bit byte
+//     offset and a 9-bit tap-validity mask; padding (layers.py:9-14) and the M tail are served
+//     by the buffer descriptor's range check (offset 0x80000000 reads zeros).
+//   * LDS image: row-major 128-byte rows, chunk index XOR ((row>>1)&7): conflict-free for the
+//     ds_read_b128 fragment reads (16 rows x one chunk per 16-lane group) and the ds_write_b128
+//     staging writes.
+//   * pipeline: global loads of tile t+1 are issued before the MFMAs of tile t and written to the
+//     other LDS buffer after them; one barrier per K tile.
+#include "yolo_internal.h"
+
+namespace yolo {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+
+#define INVALID_OFF 0x80000000u
+
+template <typename T>
+__device__ __forceinline__ float4v mma_chunk(const uint4v &a, const uint4v &b, float4v c);
+
+template <>
+__device__ __forceinline__ float4v mma_chunk<_Float16>(const uint4v &a, const uint4v &b, float4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+
+// fp32 operands: element e of every lane's chunk feeds MFMA e, so the four 16x16x4 steps cover
+// k = {e, 4+e, 8+e, 12+e}: all 16 k of the 4 chunks (exact fp32 FMA chain).
+template <>
+__device__ __forceinline__ float4v mma_chunk<float>(const uint4v &a, const uint4v &b, float4v c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), c, 0, 0, 0);
+    return c;
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+
+// WM x WN waves; a wave owns TM*16 couts x TP*16 pixels.
+template <typename T, int WM, int WN, int TM, int TP, bool PERCHUNK>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
+    static_assert(WM * WN == 4, "four waves per workgroup");
+    constexpr int NA = WM * TM * 16;        // couts per block
+    constexpr int NB = WN * TP * 16;        // pixels per block
+    constexpr int LA = NA / 32;             // 16-byte staging loads per thread per tile
+    constexpr int LB = NB / 32;
+    constexpr int CH = 4 * TM;              // contiguous channels a lane owns per pixel
+    constexpr int ES = (int)sizeof(T);
+    constexpr int EPC = 16 / ES;
+    constexpr int TILE_BYTES = (NA + NB) * 128;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware bijective remap: the 8 XCDs get contiguous ranges of (pixel-tile, cout-tile) so the
+    // cout tiles of one pixel tile run back to back on one XCD and share its L2 (speed only).
+    int bid = blockIdx.x;
+    {
+        const int q = p.n_blocks >> 3, r = p.n_blocks & 7, x = bid & 7, y = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int nt = bid % p.n_tiles_n;
+    const int mt = bid / p.n_tiles_n;
+    const int n0 = nt * NA;
+    const int m0 = mt * NB;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wgt), 0, p.wgt_bytes, 0x00020000);
+
+    // ---- staging geometry: thread -> (row r0 + 32 i, chunk c) of each tile ------------------
+    const int c = tid & 7;
+    const int r0 = tid >> 3;
+    const int sw = (c ^ ((r0 >> 1) & 7)) << 4;      // swizzled chunk byte offset (same for every i)
+
+    uint32_t a_off[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int r = r0 + 32 * i;
+        const int ws = r / (TM * 16), R = r % (TM * 16);
+        const int tm = R >> 4, g = (R >> 2) & 3, j = R & 3;
+        const int ch = ws * (TM * 16) + g * CH + 4 * tm + j;    // LDS row R holds this cout
+        a_off[i] = (uint32_t)(n0 + ch) * p.wrow_bytes + c * 16;
+    }
+    uint32_t b_base[LB], b_mask[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / p.HoWo;
+        const int rem = mm - n * p.HoWo;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        const long long e = (long long)n * p.in_img_stride + ((long long)iy0 * p.W + ix0) * p.in_ld + p.in_coff;
+        b_base[i] = (uint32_t)(e * ES) + (PERCHUNK ? 0 : c * 16);
+        uint32_t mask = 0;
+        if (ok) {
+            for (int t = 0; t < p.taps; ++t) {
+                const int kh = t / p.ksize, kw = t - kh * p.ksize;
+                if ((unsigned)(iy0 + kh) < (unsigned)p.H && (unsigned)(ix0 + kw) < (unsigned)p.W) mask |= 1u << t;
+            }
+        }
+        b_mask[i] = mask;
+    }
+
+    uint4v ra[LA], rb[LB];
+
+    auto load_tile = [&](int kt) {
+        const uint32_t ka = (uint32_t)kt * 128;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_off[i] + ka, 0, 0);
+        int tap;
+        uint32_t koff;
+        if (PERCHUNK) {
+            const int kc = kt * 8 + c;
+            tap = kc >> p.cpt_shift;
+            koff = (uint32_t)(kc & ((1 << p.cpt_shift) - 1)) * 16;
+        } else {
+            tap = kt / p.tiles_per_tap;
+            koff = (uint32_t)(kt - tap * p.tiles_per_tap) * 128;
+        }
+        const int kh = p.ksize == 3 ? (tap * 11) >> 5 : 0;
+        const int kw = tap - kh * p.ksize;
+        const uint32_t toff = (uint32_t)((kh * p.W + kw) * p.in_ld * ES) + koff;
+        const bool tap_ok = tap < p.taps;
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const bool ok = tap_ok && ((b_mask[i] >> (tap & 15)) & 1u);
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? b_base[i] + toff : INVALID_OFF, 0, 0);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char *A = smem + buf * TILE_BYTES;
+        unsigned char *B = A + NA * 128;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) *reinterpret_cast<uint4v *>(A + (r0 + 32 * i) * 128 + sw) = ra[i];
+#pragma unroll
+        for (int i = 0; i < LB; ++i) *reinterpret_cast<uint4v *>(B + (r0 + 32 * i) * 128 + sw) = rb[i];
+    };
+
+    float4v acc[TM][TP];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    auto compute = [&](int buf) {
+        const unsigned char *A = smem + buf * TILE_BYTES + (wm * TM * 16 + fr) * 128;
+        const unsigned char *B = smem + buf * TILE_BYTES + NA * 128 + (wn * TP * 16 + fr) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int so = (((ks * 4 + fq) ^ (fr >> 1)) & 7) << 4;
+            uint4v fa[TM], fb[TP];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const uint4v *>(A + a * 16 * 128 + so);
+#pragma unroll
+            for (int b = 0; b < TP; ++b) fb[b] = *reinterpret_cast<const uint4v *>(B + b * 16 * 128 + so);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TP; ++b) acc[a][b] = mma_chunk<T>(fa[a], fb[b], acc[a][b]);
+        }
+    };
+
+    // ---- main loop ------------------------------------------------------------------------
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < p.ktiles; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < p.ktiles;
+        if (more) load_tile(kt + 1);
+        compute(cur);
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, leaky, residual, store --------------------------------------------
+    const int cbase = n0 + wm * (TM * 16) + fq * CH;    // first cout of this lane
+    if (cbase >= p.Cout) return;
+    float bias[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) bias[i] = p.bias[cbase + i];      // bias is padded to 128 couts
+    const int nvalid = p.Cout - cbase < CH ? p.Cout - cbase : CH;
+
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+        const int m = m0 + wn * (TP * 16) + b * 16 + fr;
+        if (m >= p.M) continue;
+        const int n = m / p.HoWo;
+        const int rem = m - n * p.HoWo;
+        float v[CH];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * a + j] = acc[a][b][j] + bias[4 * a + j];
+        if (p.leaky) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) v[i] = fmaxf(0.1f * v[i], v[i]);       // layers.py:6,51
+        }
+        if (p.has_res) {        // shortcut: plain add, no activation afterwards (layers.py:102)
+            const T *rp = reinterpret_cast<const T *>(p.res) + (long long)n * p.res_img_stride + (long long)rem * p.res_ld + cbase;
+            if (p.vec_res) {
+#pragma unroll
+                for (int q = 0; q < CH / EPC; ++q) {
+                    const uint4v u = *reinterpret_cast<const uint4v *>(rp + q * EPC);
+                    T t[EPC];
+                    __builtin_memcpy(t, &u, 16);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[q * EPC + e] += to_f32<T>(t[e]);
+                }
+            } else {
+                for (int i = 0; i < nvalid; ++i) v[i] += to_f32<T>(rp[i]);
+            }
+        }
+        // output position(s)
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        long long off[4];
+        int npos = 1;
+        if (p.outmode == OUT_NORMAL) {
+            off[0] = (long long)n * p.out_img_stride + (long long)rem * p.out_ld + cbase;
+        } else if (p.outmode == OUT_UP2) {      // out[2oy+dy][2ox+dx] = v  (layers.py:115)
+            const long long W2 = 2LL * p.Wo;
+            const long long base = (long long)n * p.out_img_stride + ((2LL * oy) * W2 + 2LL * ox) * p.out_ld + cbase;
+            off[0] = base; off[1] = base + p.out_ld; off[2] = base + W2 * p.out_ld; off[3] = base + (W2 + 1) * p.out_ld;
+            npos = 4;
+        } else {                                // reorg: block-major space-to-depth (layers.py:92-96)
+            const int W2 = p.Wo >> 1;
+            off[0] = (long long)n * p.out_img_stride + ((long long)(oy >> 1) * W2 + (ox >> 1)) * p.out_ld
+                     + ((oy & 1) * 2 + (ox & 1)) * p.Cout + cbase;
+        }
+        if (p.out_f32) {
+            float *op = reinterpret_cast<float *>(p.out);
+            for (int q = 0; q < npos; ++q) {
+                if (p.vec_out) {
+#pragma unroll
+                    for (int i = 0; i < CH / 4; ++i)
+                        *reinterpret_cast<float4v *>(op + off[q] + 4 * i) = float4v{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+                } else {
+                    for (int i = 0; i < nvalid; ++i) op[off[q] + i] = v[i];
+                }
+            }
+        } else {
+            T *op = reinterpret_cast<T *>(p.out);
+            T t[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) t[i] = (T)v[i];
+            for (int q = 0; q < npos; ++q) {
+                if (p.vec_out) {
+#pragma unroll
+                    for (int i = 0; i < CH / EPC; ++i) {
+                        uint4v u;
+                        __builtin_memcpy(&u, t + i * EPC, 16);
+                        *reinterpret_cast<uint4v *>(op + off[q] + i * EPC) = u;
+                    }
+                } else {
+                    for (int i = 0; i < nvalid; ++i) op[off[q] + i] = t[i];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, bool PC>
+static hipError_t launch_cfg(const ConvParams &p0, int cfg, hipStream_t s) {
+    ConvParams p = p0;
+    int na, nb;
+    switch (cfg) {
+    case CFG_N128: na = 128; nb = 128; break;
+    case CFG_N64: na = 64; nb = 256; break;
+    default: na = 32; nb = 256; break;
+    }
+    p.n_tiles_n = (p.Cout + na - 1) / na;
+    const long long mt = ((long long)p.M + nb - 1) / nb;
+    const long long blocks = mt * p.n_tiles_n;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    p.n_blocks = (int)blocks;
+    dim3 grid((unsigned)blocks), block(256);
+    switch (cfg) {
+    case CFG_N128: hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 4, 4, PC>), grid, block, 0, s, p); break;
+    case CFG_N64: hipLaunchKernelGGL((conv_igemm_kernel<T, 1, 4, 4, 4, PC>), grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((conv_igemm_kernel<T, 1, 4, 2, 4, PC>), grid, block, 0, s, p); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_conv(const ConvParams &p, int dtype, int cfg, bool perchunk, hipStream_t s) {
+    if (dtype == YOLO_DTYPE_F16)
+        return perchunk ? launch_cfg<_Float16, true>(p, cfg, s) : launch_cfg<_Float16, false>(p, cfg, s);
+    return perchunk ? launch_cfg<float, true>(p, cfg, s) : launch_cfg<float, false>(p, cfg, s);
+}
+
+}  // namespace yolo

@@ -1,0 +1,213 @@
+// YOLO head decode + greedy NMS on the device.
+//
+// decode_kernel   replaces net/v2.py:93-119 and net/v3.py:109-136 (the triple Python loop):
+//                 one thread per (cell, anchor) row; rows that pass the score threshold are
+//                 appended (wavefront-aggregated atomic) to a per-image candidate list together
+//                 with their scan index.
+// nms_kernel      replaces net/base.py:180-209: one workgroup per image; candidates are sorted in
+//                 LDS by (prob descending, scan index ascending) == Python's stable
+//                 list.sort(key=prob, reverse=True) over the scan-ordered list (base.py:199),
+//                 then suppressed greedily; IoU in float64 exactly as base.py:180-192 computes it
+//                 (x,y float32; w,h float64; union floored at 1e-8; suppress when iou >= thr).
+#include "yolo_internal.h"
+
+namespace yolo {
+
+__device__ __forceinline__ float sigmoid_f32(float x) { return 1.f / (1.f + expf(-x)); }   // base.py:171-172
+
+__global__ void __launch_bounds__(256) decode_kernel(const DecodeParams p) {
+    const int width = 5 + p.n_classes;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < p.total_rows; row += stride) {
+        const int b = (int)(row / p.rows);
+        const int r = (int)(row - (long long)b * p.rows);
+        const float *t = p.logits + row * width;
+        const float po = sigmoid_f32(t[4]);
+        float prob;
+        int cls = 0;
+        if (p.version == 3) {
+            prob = po;                                  // v3.py:123 p = prob_obj
+            if (prob < p.threshold) continue;           // v3.py:124 (p == thr is kept)
+            float best = sigmoid_f32(t[5]);
+            for (int k = 1; k < p.n_classes; ++k) {     // v3.py:120-121 argmax of sigmoid(cls): first max wins
+                const float s = sigmoid_f32(t[5 + k]);
+                if (s > best) { best = s; cls = k; }
+            }
+        } else {
+            if (po < p.threshold) continue;             // p = po * pc <= po: cheap early out, same result
+            float mx = t[5];
+            for (int k = 1; k < p.n_classes; ++k) mx = fmaxf(mx, t[5 + k]);
+            float sum = 0.f;
+            for (int k = 0; k < p.n_classes; ++k) sum += expf(t[5 + k] - mx);      // base.py:175-177
+            float best = expf(t[5] - mx) / sum;
+            for (int k = 1; k < p.n_classes; ++k) {
+                const float s = expf(t[5 + k] - mx) / sum;
+                if (s > best) { best = s; cls = k; }
+            }
+            prob = po * best;                           // v2.py:106
+            if (prob < p.threshold) continue;           // v2.py:107
+        }
+        int s = 0;
+        while (s + 1 < p.n_scales && r >= p.sc[s + 1].row0) ++s;
+        const DecodeScale &sc = p.sc[s];
+        const int rr = r - sc.row0;
+        const int a = rr % sc.na;
+        const int cell = rr / sc.na;
+        const int cw = cell % sc.w, cy = cell / sc.w;
+        Candidate c;
+        c.x = (sigmoid_f32(t[0]) + (float)cw) / (float)sc.w;            // v2.py:112 / v3.py:129 (float32)
+        c.y = (sigmoid_f32(t[1]) + (float)cy) / (float)sc.h;
+        c.w = (sc.aw[a] * (double)expf(t[2])) / (double)sc.w;           // float64: anchors are np.float64
+        c.h = (sc.ah[a] * (double)expf(t[3])) / (double)sc.h;
+        c.prob = prob;
+        c.cls = cls;
+        c.scan = (unsigned)r;
+        c.pad_ = 0;
+        const int slot = atomicAdd(&p.cand_count[b], 1);
+        if (slot < p.cap) reinterpret_cast<Candidate *>(p.cand)[(long long)b * p.cap + slot] = c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned orderable(float f) {        // monotone float -> uint
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// LDS carve (dynamic, 16-byte aligned): idx u16[n2] | union { key u64[n2] ; boxes } | kept u16[cap]
+__global__ void __launch_bounds__(1024) nms_kernel(const NmsParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    int count = p.cand_count[b];
+    int status = 0;
+    if (count > p.cap) { count = p.cap; status = 1; }
+    const int n = count;
+    if (n == 0) {
+        if (tid == 0) { p.counts[b] = 0; p.status[b] = status; }
+        return;
+    }
+    int n2 = 2;
+    while (n2 < n) n2 <<= 1;
+    int cap2 = 2;
+    while (cap2 < p.cap) cap2 <<= 1;
+
+    unsigned short *idx = reinterpret_cast<unsigned short *>(lds);
+    unsigned char *u = lds + (((size_t)cap2 * 2 + 15) & ~(size_t)15);
+    unsigned long long *key = reinterpret_cast<unsigned long long *>(u);
+    const Candidate *cand = p.cand + (long long)b * p.cap;
+
+    for (int i = tid; i < n2; i += nthr) {
+        unsigned long long k = ~0ULL;
+        if (i < n) k = ((unsigned long long)(~orderable(cand[i].prob)) << 32) | cand[i].scan;
+        key[i] = k;
+        idx[i] = (unsigned short)i;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n2 >> 1); t += nthr) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool up = (i & k) == 0;
+                const unsigned long long ki = key[i], kl = key[l];
+                if ((ki > kl) == up) {
+                    key[i] = kl; key[l] = ki;
+                    const unsigned short s = idx[i]; idx[i] = idx[l]; idx[l] = s;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // sorted boxes into LDS (aliases the key array: read idx first, barrier, then overwrite)
+    double *bw = reinterpret_cast<double *>(u);
+    double *bh = bw + n;
+    float *bx = reinterpret_cast<float *>(bh + n);
+    float *by = bx + n;
+    int *bc = reinterpret_cast<int *>(by + n);
+    unsigned char *alive = reinterpret_cast<unsigned char *>(bc + n);
+    unsigned short *kept = reinterpret_cast<unsigned short *>(u + (((size_t)cap2 * 29 + 15) & ~(size_t)15));
+    __syncthreads();
+    for (int i = tid; i < n; i += nthr) {
+        const Candidate c = cand[idx[i]];
+        bw[i] = c.w; bh[i] = c.h; bx[i] = c.x; by[i] = c.y; bc[i] = c.cls; alive[i] = 1;
+    }
+    __syncthreads();
+
+    const double thr = p.iou_threshold;
+    int nk = 0;
+    bool truncated = false;
+    for (int i = 0; i < n; ++i) {
+        if (!alive[i]) continue;                // final: every earlier survivor's pass ended with a barrier
+        if (nk == p.max_boxes) { truncated = true; break; }
+        if (tid == 0) kept[nk] = (unsigned short)i;
+        ++nk;
+        const double w1 = bw[i], h1 = bh[i];
+        const double x1 = (double)bx[i], y1 = (double)by[i];
+        const double ax1 = (x1 - w1 / 2.) * 1., ay1 = (y1 - h1 / 2.) * 1.;      // base.py:267-272
+        const double ax2 = (x1 + w1 / 2.) * 1., ay2 = (y1 + h1 / 2.) * 1.;
+        const double a1 = w1 * h1;
+        const int c1 = bc[i];
+        for (int j = i + 1 + tid; j < n; j += nthr) {
+            if (!alive[j]) continue;
+            if (p.mode == YOLO_NMS_PER_CLASS && bc[j] != c1) continue;
+            const double w2 = bw[j], h2 = bh[j];
+            const double x2 = (double)bx[j], y2 = (double)by[j];
+            const double bx1 = (x2 - w2 / 2.) * 1., by1 = (y2 - h2 / 2.) * 1.;
+            const double bx2 = (x2 + w2 / 2.) * 1., by2 = (y2 + h2 / 2.) * 1.;
+            const double iw = fmax(fmin(ax2, bx2) - fmax(ax1, bx1), 0.);
+            const double ih = fmax(fmin(ay2, by2) - fmax(ay1, by1), 0.);
+            const double inter = iw * ih;
+            const double uni = fmax(a1 + w2 * h2 - inter, 1e-8);                // base.py:190
+            if (inter / uni >= thr) alive[j] = 0;                               // base.py:204
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (truncated) status |= 2;
+    for (int k = tid; k < nk; k += nthr) {
+        const int i = kept[k];
+        yolo_box o;
+        o.x = bx[i]; o.y = by[i]; o.w = (float)bw[i]; o.h = (float)bh[i];
+        o.class_idx = bc[i];
+        const int ci = idx[i];
+        o.prob = cand[ci].prob;
+        p.boxes[(long long)b * p.max_boxes + k] = o;
+        if (p.keep_idx) p.keep_idx[(long long)b * p.max_boxes + k] = ci;
+    }
+    if (tid == 0) { p.counts[b] = nk; p.status[b] = status; }
+}
+
+size_t nms_lds_bytes(int cap) {
+    size_t cap2 = 2;
+    while ((int)cap2 < cap) cap2 <<= 1;
+    size_t a = (cap2 * 2 + 15) & ~(size_t)15;           // idx
+    size_t u = (cap2 * 29 + 15) & ~(size_t)15;          // max(key 8 B, boxes 8+8+4+4+4+1 = 29 B) per entry
+    return a + u + cap2 * 2 + 64;                       // + kept
+}
+
+hipError_t launch_decode(const DecodeParams &p, int batch, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(p.cand_count, 0, sizeof(int) * (size_t)batch, s);
+    if (e != hipSuccess) return e;
+    long long g = (p.total_rows + 255) / 256;
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)g), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_nms(const NmsParams &p, int batch, hipStream_t s) {
+    const size_t lds = nms_lds_bytes(p.cap);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL(nms_kernel, dim3((unsigned)batch), dim3(1024), lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace yolo

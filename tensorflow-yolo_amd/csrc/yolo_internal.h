@@ -1,0 +1,190 @@
+// Internal interfaces of libyolo_hip.so (not part of the C ABI; see include/yolo_hip.h).
+//
+// Data layout in HBM (DESIGN.md "Layout"):
+//   activations  NHWC, element type T (fp16 or fp32), addressed as strided views
+//                (pixel stride `ld`, first channel `coff`, image stride) so that
+//                route/concat, upsample and reorg never copy: producers write slices.
+//   weights      [Cout_pad][K] with K = (kh, kw, cin) in 16-byte chunks, BN folded,
+//                rows zero-padded to a multiple of 128, K zero-padded to 8 chunks.
+//   head logits  float32 in the reference's layout (net/v2.py:52-59, net/layers.py:119-133).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "yolo_hip.h"
+
+namespace yolo {
+
+enum OutMode { OUT_NORMAL = 0, OUT_UP2 = 1, OUT_REORG2 = 2 };
+enum BufId { BUF_NONE = -1, BUF_USER_OUT = -2, BUF_USER_IN = -3 };
+enum ConvCfg { CFG_N128 = 0, CFG_N64 = 1, CFG_N32 = 2 };   // cout-tile width of the block
+enum KernelKind { K_PREP = 0, K_CONV = 1, K_POOL = 2, K_ELTWISE = 3 };
+
+// A strided NHWC view inside a planned buffer.
+struct View {
+    int buf = BUF_NONE;
+    int H = 0, W = 0, C = 0;
+    int ld = 0;                 // elements between consecutive pixels
+    int coff = 0;               // first channel inside the pixel
+    long long img_stride = 0;   // elements between consecutive images
+    long long base = 0;         // extra element offset (head scale offset inside the output)
+    bool f32 = false;           // float32 elements whatever the net dtype (head logits)
+};
+
+struct Buffer {
+    long long elems_per_image = 0;  // elements per image
+    int esize = 2;
+    int first = 1 << 30, last = -1; // kernel indices of first write / last access
+    size_t offset = 0;              // bytes inside the workspace
+    size_t bytes = 0;               // for max_batch
+    bool is_concat = false;
+};
+
+// ---- device-side parameter blocks -----------------------------------------------------
+struct ConvParams {
+    const void *in;            // base of the input BUFFER (view offsets are folded into byte offsets)
+    const void *wgt;
+    const float *bias;
+    const void *res;           // residual tensor base (element pointer incl. coff) or null
+    void *out;                 // output base pointer incl. view base / coff
+    uint32_t in_bytes, wgt_bytes;
+    int H, W, in_ld, in_coff;
+    long long in_img_stride;
+    int Ho, Wo, HoWo, M;
+    int Cout, out_ld;
+    long long out_img_stride;
+    int res_ld;
+    long long res_img_stride;
+    int ksize, stride, pad, taps;
+    int ktiles, tiles_per_tap, cpt_shift;
+    uint32_t wrow_bytes;
+    int leaky, has_res, outmode, out_f32, vec_out, vec_res;
+    int n_tiles_n, n_blocks;
+};
+
+struct PrepParams {            // float32 NHWC [B,H,W,C] -> T NHWC [B,H,W,Cpad], zero fill
+    const float *in;
+    void *out;
+    long long pixels;
+    int C, Cpad;
+};
+
+struct PoolParams {            // net/layers.py:70-81
+    const void *in;
+    void *out;
+    int H, W, C, in_ld, Ho, Wo, out_ld, stride;
+    long long in_img_stride, out_img_stride;
+    long long total;           // B*Ho*Wo*(C/EPC) work items
+};
+
+struct EltParams {             // generic fallback: out[map(p)] = a[p] (+ b[p]); scalar, any view
+    const void *a;
+    const void *b;
+    void *out;
+    int H, W, C, a_ld, b_ld, out_ld, outmode, out_f32, a_f32;
+    long long a_img_stride, b_img_stride, out_img_stride;
+    long long total;           // B*H*W*C
+};
+
+struct DecodeScale {
+    int row0, h, w, na;
+    double aw[YOLO_MAX_ANCHORS], ah[YOLO_MAX_ANCHORS];
+};
+
+struct DecodeParams {
+    const float *logits;       // [B, rows, 5+C]
+    int version, n_classes, rows, n_scales;
+    DecodeScale sc[YOLO_MAX_SCALES];
+    float threshold;
+    int cap;
+    void *cand;                // Candidate[B][cap]
+    int *cand_count;           // [B]
+    long long total_rows;      // B*rows
+};
+
+struct Candidate {             // 40 bytes
+    float x, y;
+    double w, h;               // the reference computes w,h in float64 (anchors are np.float64)
+    float prob;
+    int cls;
+    unsigned scan;             // scan index (cy, cw, anchor) across scales: stable-sort tie break
+    int pad_;
+};
+
+struct NmsParams {
+    const Candidate *cand;
+    const int *cand_count;
+    int cap, max_boxes, mode;
+    double iou_threshold;
+    yolo_box *boxes;
+    int *counts;
+    int *status;
+    int *keep_idx;             // optional [B][max_boxes]: candidate index of each survivor
+};
+
+// ---- launchers (kernels.hip / detect.hip) ------------------------------------------------
+hipError_t launch_conv(const ConvParams &p, int dtype, int cfg, bool perchunk, hipStream_t s);
+hipError_t launch_prep(const PrepParams &p, int dtype, hipStream_t s);
+hipError_t launch_pool(const PoolParams &p, int dtype, hipStream_t s);
+hipError_t launch_eltwise(const EltParams &p, int dtype, hipStream_t s);
+hipError_t launch_decode(const DecodeParams &p, int batch, hipStream_t s);
+hipError_t launch_nms(const NmsParams &p, int batch, hipStream_t s);
+size_t nms_lds_bytes(int cap);
+
+// ---- plan -----------------------------------------------------------------------------------
+struct Kernel {
+    int kind = 0;
+    int layer = -1;            // reference layer index this kernel materialises
+    int src_layer = -1;        // conv: the conv layer whose weights it uses
+    View in, in2, out;
+    // conv
+    int ksize = 0, stride = 0, cout = 0, cin = 0, cin_s = 0, leaky = 0, outmode = 0, has_res = 0;
+    int cfg = 0, perchunk = 0, cpt = 0, ktiles = 0;
+    size_t w_off = 0, b_off = 0, w_bytes = 0;   // inside the device weight blob
+    size_t w_src = 0;                           // first float of this conv in the Darknet stream
+    int batch_norm = 0;
+    // pool
+    int pool_stride = 0;
+    std::string note;
+};
+
+struct LayerInfo {
+    yolo_layer_desc d;
+    int H = 0, W = 0, C = 0;
+    std::vector<int> consumers;
+    int fused_into = -1;       // conv kernel (layer idx) that produces this layer's tensor
+    View view;                 // where the layer's output lives (after alias resolution)
+    bool materialised = false;
+};
+
+}  // namespace yolo
+
+struct yolo_net {
+    yolo_net_options opt;
+    std::vector<yolo::LayerInfo> layers;
+    std::vector<yolo::Kernel> kernels;
+    std::vector<yolo::Buffer> buffers;
+    yolo_head_desc head;
+    size_t weight_count = 0;       // floats in the Darknet stream
+    size_t weights_bytes = 0;
+    size_t act_bytes = 0;          // activation part of the workspace
+    size_t logits_off = 0, cand_off = 0, count_off = 0;
+    size_t workspace_bytes = 0;
+    size_t out_count = 0;          // floats per image of the head output
+    double flops_per_image = 0;
+    int esize = 2, epc = 8;
+    // bound device memory
+    unsigned char *dev_weights = nullptr;
+    unsigned char *dev_ws = nullptr;
+    size_t dev_ws_bytes = 0;
+    bool weights_loaded = false;
+};
+
+namespace yolo {
+int plan_network(yolo_net *net, const yolo_layer_desc *layers, int n, std::string &err);
+int pack_weights(const yolo_net *net, const float *host, size_t n, std::vector<unsigned char> &blob, std::string &err);
+std::string describe(const yolo_net *net);
+void set_error(const std::string &s);
+}  // namespace yolo

@@ -1,0 +1,145 @@
+"""Shared helpers of the HIP backend: result type, Darknet weight-file reading, NMS entry,
+image listing / preprocessing / drawing.
+
+Counterpart of the reference's net/base.py; the arithmetic that file does in NumPy/Python
+(sigmoid/softmax/IoU/NMS, :171-209) runs here in libyolo_hip kernels instead.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .. import _hip
+
+COLORS = [(0, 0, 255), (0, 255, 0), (255, 0, 0), (0, 255, 255), (255, 255, 0), (255, 0, 255)]    # BGR, as the reference draws
+IMAGE_EXTENSIONS = ("jpg", "bmp", "png", "gif")
+
+
+class BoundingBox(object):
+    """Same fields and helpers as the reference's result type (net/base.py:257-272)."""
+
+    def __init__(self, x=0., y=0., w=0., h=0., cx=0, cy=0, class_idx=-1, prob=-1.):
+        self.x, self.y, self.w, self.h = x, y, w, h
+        self.cx, self.cy = cx, cy
+        self.class_idx = class_idx
+        self.prob = prob
+
+    def get_top_left(self, h=1., w=1.):
+        return (self.x - self.w / 2.) * w, (self.y - self.h / 2.) * h
+
+    def get_bottom_right(self, h=1., w=1.):
+        return (self.x + self.w / 2.) * w, (self.y + self.h / 2.) * h
+
+    def __repr__(self):
+        return "BoundingBox(x=%.4f, y=%.4f, w=%.4f, h=%.4f, class_idx=%d, prob=%.4f)" % (
+            self.x, self.y, self.w, self.h, self.class_idx, self.prob)
+
+
+def boxes_from_records(records):
+    return [[BoundingBox(x=r[0], y=r[1], w=r[2], h=r[3], class_idx=r[4], prob=r[5]) for r in img] for img in records]
+
+
+def non_maximum_suppression(boxes, iou_threshold, per_class=False):
+    """Greedy NMS of a host list of BoundingBox on the GPU (yolo_nms_host).
+    Semantics of the reference (net/base.py:195-209): stable sort by prob descending, suppress
+    when IoU >= threshold, class-agnostic unless per_class."""
+    n = len(boxes)
+    if n == 0:
+        return []
+    xywh = np.array([[b.x, b.y, b.w, b.h] for b in boxes], dtype=np.float64)
+    prob = np.array([b.prob for b in boxes], dtype=np.float32)
+    cls = np.array([b.class_idx for b in boxes], dtype=np.int32)
+    keep = np.zeros(n, dtype=np.int32)
+    n_keep = C.c_int32(0)
+    lib = _hip.lib()
+    _hip.check(lib.yolo_nms_host(xywh.ctypes.data, prob.ctypes.data, cls.ctypes.data, n, float(iou_threshold),
+                                 _hip.NMS_PER_CLASS if per_class else _hip.NMS_AGNOSTIC, keep.ctypes.data,
+                                 C.byref(n_keep)), "yolo_nms_host")
+    return [boxes[i] for i in keep[:n_keep.value]]
+
+
+# ---- Darknet .weights files ----------------------------------------------------------------------
+def read_darknet_weights(weights_path, version):
+    """Header + float32 body.  v2 files: int32 major, minor, revision and a 4-byte `seen`
+    (reference net/v2.py:69-75 reads 4 bytes for both header generations); v3 files: five int32
+    (reference net/v3.py:102).  Returns (header tuple, float32 array)."""
+    with open(weights_path, "rb") as f:
+        if version == "v3":
+            header = tuple(int(v) for v in np.fromfile(f, count=5, dtype=np.int32))
+        else:
+            major, minor, revision = (int(v) for v in np.fromfile(f, count=3, dtype=np.int32))
+            seen = int(np.fromfile(f, count=1, dtype=np.int32)[0])
+            header = (major, minor, revision, seen)
+        body = np.fromfile(f, dtype=np.float32)
+    return header, body
+
+
+def write_darknet_weights(weights_path, body, version):
+    """Inverse of read_darknet_weights (used for the synthetic weight files)."""
+    with open(weights_path, "wb") as f:
+        if version == "v3":
+            np.array([0, 2, 0, 0, 0], dtype=np.int32).tofile(f)
+        else:
+            np.array([0, 1, 0, 0], dtype=np.int32).tofile(f)
+        np.ascontiguousarray(body, dtype=np.float32).tofile(f)
+
+
+# ---- images ---------------------------------------------------------------------------------------
+def load_image_paths(path_to_img_dir):
+    """Files of the directory with an image extension, os.listdir order (reference net/base.py:64-66)."""
+    root = os.path.abspath(path_to_img_dir)
+    return [os.path.join(root, f) for f in os.listdir(path_to_img_dir) if f.lower().endswith(IMAGE_EXTENSIONS)]
+
+
+def preprocess_image(image_path, new_shape):
+    """decode -> stretch-resize to (h, w) -> RGB -> [0,1] float (reference net/base.py:115-155,
+    which uses OpenCV: bilinear, no letterbox).  OpenCV is not available to this package; Pillow's
+    bilinear resample stands in, so pixel values can differ from cv2.resize in the last bits
+    (documented: parity for this step is unpinned)."""
+    from PIL import Image
+    try:
+        img = Image.open(image_path)
+        img.load()
+    except Exception:
+        print("Failed to read {}".format(image_path))
+        return None
+    img = img.convert("RGB").resize((int(new_shape[1]), int(new_shape[0])), Image.BILINEAR)
+    return np.asarray(img, dtype=np.float64) / 255.
+
+
+def generate_test_batch(img_paths, batch_size, input_shape):
+    """Yields ([B,h,w,c] float array, paths); the last batch may be short (reference net/base.py:158-168)."""
+    for start in range(0, len(img_paths), batch_size):
+        chunk = img_paths[start:start + batch_size]
+        images = []
+        for p in chunk:
+            image = preprocess_image(p, input_shape)
+            if image is None:
+                raise IOError("cannot read image {}".format(p))
+            images.append(image)
+        yield np.stack(images, axis=0), chunk
+
+
+def draw_boxes(path_to_img, boxes, class_names):
+    """Rectangles (thickness 3) + "name prob" labels in the reference's colours, scaled to the
+    original image size, top-left clamped at 0 (reference net/base.py:212-226).  Returns a PIL image."""
+    from PIL import Image, ImageDraw
+    image = Image.open(path_to_img).convert("RGB")
+    w, h = image.size
+    draw = ImageDraw.Draw(image)
+    for box in boxes:
+        tl = np.maximum(box.get_top_left(h, w), 0)
+        br = np.maximum(box.get_bottom_right(h, w), 0)
+        tl, br = (int(tl[0]), int(tl[1])), (int(br[0]), int(br[1]))
+        bgr = COLORS[box.class_idx % len(COLORS)]
+        rgb = (bgr[2], bgr[1], bgr[0])
+        draw.rectangle([tl, (max(br[0], tl[0]), max(br[1], tl[1]))], outline=rgb, width=3)
+        draw.text((tl[0], max(tl[1] - 12, 0)), "{} {:.3f}".format(class_names[box.class_idx], box.prob), fill=rgb)
+    return image
+
+
+def save_image(image, out_path):
+    out_dir = os.path.dirname(out_path)
+    if out_dir and not os.path.isdir(out_dir):
+        os.makedirs(out_dir)
+    image.save(out_path)

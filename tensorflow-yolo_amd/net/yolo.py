@@ -1,0 +1,136 @@
+"""Driver classes of the HIP backend: `Yolo.test(params)` with the reference's parameter keys,
+and the factored-out per-batch body `predict(x_batch)`.
+
+Counterpart of the reference's net/yolo.py (TEST path :41-96; binding classes :198-211).
+Training (`train`, `generate_anchors`, loss, batches) is out of scope: those entries raise.
+"""
+import os
+
+import numpy as np
+
+from .. import _hip
+from . import base, engine, v2, v3
+
+
+class Yolo(object):
+    version = None
+    # plug points, bound per version below (same names as the reference)
+    create_network = None
+    load_weights = None
+    find_bounding_boxes = None
+
+    def __init__(self):
+        self.net = None
+        self.params = None
+
+    # ---- out of scope for an inference backend ------------------------------------------------
+    def train(self, params):
+        raise NotImplementedError("train mode is not supported by the HIP inference backend")
+
+    def generate_anchors(self, params):
+        raise NotImplementedError("anchor mode is not supported by the HIP inference backend")
+
+    def create_loss_fn(self, batch_size, net, anchors, class_names):
+        raise NotImplementedError("training is not supported by the HIP inference backend")
+
+    def make_batch(self, net, annotations, batch_size, anchors, class_names, augment_prob):
+        raise NotImplementedError("training is not supported by the HIP inference backend")
+
+    def create_train_optimizer(self, loss_fn, learning_rate):
+        raise NotImplementedError("training is not supported by the HIP inference backend")
+
+    # ---- network lifecycle ----------------------------------------------------------------------
+    def build(self, anchors, class_names, input_shape=(416, 416, 3), dtype="fp32", max_batch=1,
+              weights=None, weights_path=None, **engine_kw):
+        """create_network + compile for the GPU + load weights (array or Darknet file)."""
+        anchors = np.reshape(anchors, [-1, 2])
+        self.anchors, self.class_names = anchors, list(class_names)
+        net = type(self).create_network(anchors, class_names, False, input_shape=tuple(input_shape))
+        net.engine = engine.HipNetwork(net, dtype=dtype, max_batch=max_batch, **engine_kw)
+        if self.version != "v3":
+            h, w, _ = net[-1].out.hwc
+            net.engine.set_head(engine.head_desc_v2(h, w, anchors, len(class_names)))
+        if weights is not None:
+            v3.attach_weights(net, weights)
+        elif weights_path is not None:
+            type(self).load_weights(net, weights_path)
+        self.net = net
+        return net
+
+    def predict(self, x_batch, threshold=0.5, iou_threshold=0.6, nms_mode=_hip.NMS_AGNOSTIC):
+        """One batch: forward + decode + NMS on the GPU (the body of the reference's test loop,
+        net/yolo.py:83-86).  x_batch: [B,H,W,C] in [0,1], RGB (NumPy or torch).
+        Returns list[B] of list[BoundingBox], each in descending-prob (stable) order."""
+        eng = self.net.engine
+        if not eng.weights_loaded:
+            raise RuntimeError("no weights loaded: call load_weights / build(weights=...) first")
+        boxes, counts, status = eng.detect(x_batch, threshold, iou_threshold, nms_mode)
+        records, _ = engine.records_to_host(boxes, counts, status)
+        return base.boxes_from_records(records)
+
+    def forward(self, x_batch):
+        """Head logits as a NumPy float32 array in the reference's layout (what sess.run returns)."""
+        return self.net.engine.forward(x_batch).cpu().numpy()
+
+    # ---- TEST mode --------------------------------------------------------------------------------
+    def test(self, params):
+        image_dir = params["image_dir"]
+        out_dir = params["out_dir"]
+        batch_size = int(params["batch_size"])
+        threshold = float(params["threshold"])
+        iou_threshold = float(params["iou_threshold"])
+        anchors = np.reshape(params["anchors"], [-1, 2])
+        class_names = params["class_names"]
+        input_shape = (int(params["input_h"]), int(params["input_w"]), int(params["input_c"]))
+        checkpoint_path = params.get("checkpoint_path", "")
+        pretrained_weights_path = params["pretrained_weights_path"]
+        cpu_only = str(params.get("cpu_only", "false")).lower() == "true"
+        dtype = params.get("dtype", "fp32")                 # new optional key; fp32 == the reference's arithmetic
+        nms_mode = {"agnostic": _hip.NMS_AGNOSTIC, "per_class": _hip.NMS_PER_CLASS}[params.get("nms_mode", "agnostic")]
+
+        image_paths = base.load_image_paths(image_dir)
+        if len(image_paths) == 0:
+            print("No test images found in {}".format(image_dir))
+            return
+        if cpu_only:
+            print("cpu_only = True is ignored: this backend runs on the MI355X only")
+
+        self.build(anchors, class_names, input_shape, dtype=dtype, max_batch=batch_size)
+        # TF checkpoints cannot be read without TensorFlow; same fallback order as the reference,
+        # whose restore failure falls through to the Darknet weights (net/base.py:55-61, net/yolo.py:72-78)
+        if checkpoint_path:
+            print("Failed to load {}: TensorFlow checkpoints are not supported by the HIP backend".format(checkpoint_path))
+        type(self).load_weights(self.net, pretrained_weights_path)
+        print("Pre-trained weights loaded.")
+
+        for x_batch, paths in base.generate_test_batch(image_paths, batch_size, input_shape):
+            net_boxes = self.predict(x_batch, threshold, iou_threshold, nms_mode)
+            for boxes, path in zip(net_boxes, paths):
+                new_img = base.draw_boxes(path, boxes, class_names)
+                file_name, file_ext = os.path.splitext(os.path.basename(path))
+                out_path = os.path.join(out_dir, "{}_out{}".format(file_name, file_ext))
+                base.save_image(new_img, out_path)
+                print("{}: Found {} objects. Saved to {}".format(file_name, len(boxes), out_path))
+        print("Done")
+
+
+class YoloV2(Yolo):
+    version = "v2"
+    create_network = staticmethod(v2.create_full_network)
+    load_weights = staticmethod(v2.load_weights)
+    find_bounding_boxes = staticmethod(v2.find_bounding_boxes)
+
+
+class YoloV2Tiny(Yolo):
+    """Not in the reference (it ships only the tiny-voc anchors); same plug points."""
+    version = "v2-tiny"
+    create_network = staticmethod(v2.create_tiny_network)
+    load_weights = staticmethod(v2.load_weights)
+    find_bounding_boxes = staticmethod(v2.find_bounding_boxes)
+
+
+class YoloV3(Yolo):
+    version = "v3"
+    create_network = staticmethod(v3.create_network)
+    load_weights = staticmethod(v3.load_weights)
+    find_bounding_boxes = staticmethod(v3.find_bounding_boxes)

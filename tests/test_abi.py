@@ -1,0 +1,126 @@
+"""CPU: the C-ABI library loads, exports every symbol include/yolo_hip.h declares, and its
+device-free half (planner, sizes, descriptions, argument checking) behaves.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, new_graph
+from oracle import cases
+from tensorflow_yolo_amd import _hip
+from tensorflow_yolo_amd.net import engine, layers as PL, v2, v3
+
+NAMES80 = ["c%d" % i for i in range(80)]
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "yolo_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(yolo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(_hip.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libyolo_hip.so does not export %s" % n
+    assert sorted(_hip.SIGNATURES) == names, "ctypes binding and header disagree"
+    assert _hip.lib().yolo_hip_abi_version() == _hip.ABI_VERSION
+
+
+def test_struct_layouts_match_the_header():
+    assert C.sizeof(_hip.Box) == 24
+    assert C.sizeof(_hip.LayerDesc) == 4 * (2 + 4 + 3 + 2 + 3 + 1) + 4 + 8 * 16      # one int of padding before the doubles
+    assert C.sizeof(_hip.NetOptions) == 32
+    assert C.sizeof(_hip.HeadDesc) == 4 * 3 + 4 * 12 + 4 + 8 * 64
+
+
+def test_plan_yolov3_608():
+    net = v3.create_network(np.reshape(cases.COCO_V3_ANCHORS, [-1, 2]), NAMES80, False, input_shape=(608, 608, 3))
+    p = engine.Plan(net, dtype="fp16", max_batch=32)
+    assert p.weight_count == 62001757 and p.output_count == 22743 * 85
+    assert round(p.flops_per_image / 1e9, 3) == 140.692
+    assert p.num_kernels == 76                      # prep + 75 convs: every other layer is fused or a view
+    d = p.describe()
+    assert d.count("fused: +shortcut") == 23 and d.count("fused: upsample x2") == 2
+    assert d.count("head logits") == 3 and d.count("concat slice") == 4
+    assert p.head.version == 3 and p.head.n_scales == 3 and list(p.head.h)[:3] == [19, 38, 76]
+    assert p.workspace_bytes < 4 << 30
+    # activation buffers are reused: far less than the sum of all layer outputs (17 GB at b32)
+    assert p.workspace_bytes < 2.5e9
+
+
+def test_plan_yolov2_and_tiny():
+    net = v2.create_full_network(np.reshape(cases.COCO_V2_ANCHORS, [-1, 2]), NAMES80, False)
+    p = engine.Plan(net, dtype="fp32", max_batch=16)
+    assert p.weight_count == 50983561 and p.output_count == 13 * 13 * 425
+    assert p.num_kernels == 1 + 23 + 5              # prep, convs, pools; reorg + routes are free
+    d = p.describe()
+    assert "fused: reorg x2" in d and d.count("concat slice") == 2
+    tiny = v2.create_tiny_network(np.reshape(cases.VOC_TINY_ANCHORS, [-1, 2]), NAMES80[:20], False)
+    pt = engine.Plan(tiny, dtype="fp32", max_batch=64)
+    assert pt.weight_count == 15867885 and pt.num_kernels == 1 + 9 + 6
+
+
+def test_fallback_graph_plans():
+    g = new_graph(8, 8, 16)
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))
+    g.append(PL.max_pool2d(g[-1].out, 2, 1))
+    g.append(PL.shortcut(g[1].out, g[2].out))
+    g.append(PL.upsample(g[-1].out, 2))
+    g.append(PL.reorg(g[-1].out, 2))
+    g.append(PL.route([g[-1].out, g[3].out]))
+    p = engine.Plan(g, dtype="fp16", max_batch=2, keep_all=True)
+    d = p.describe()
+    assert "standalone shortcut add" in d and "standalone upsample" in d and "standalone reorg" in d
+    assert "convert final layer to float32" in d
+
+
+def _create(descs, n, **opt):
+    o = _hip.NetOptions(dtype=opt.get("dtype", 1), max_batch=opt.get("max_batch", 1))
+    h = C.c_void_p()
+    rc = _hip.lib().yolo_net_create(descs, n, C.byref(o), C.byref(h))
+    return rc, h
+
+
+def test_argument_errors_have_messages():
+    lib = _hip.lib()
+    g = new_graph(8, 8, 3)
+    g.append(PL.conv2d_bn_act(g[-1].out, 16, 5, 1))           # ksize 5 unsupported
+    with pytest.raises(_hip.YoloHipError, match="ksize must be 1 or 3"):
+        engine.Plan(g, dtype="fp16")
+    g = new_graph(8, 8, 3)
+    g.append(PL.conv2d_bn_act(g[-1].out, 24, 3, 1))
+    g.append(PL.conv2d_bn_act(g[-1].out, 16, 3, 1))           # Cin 24 = 3 chunks: not tileable
+    with pytest.raises(_hip.YoloHipError, match="unsupported input channel count"):
+        engine.Plan(g, dtype="fp16")
+    descs = engine.to_descs(new_graph(8, 8, 3) + [PL.max_pool2d(PL.input_layer([None, 8, 8, 3]).out, 2, 2)][:0])
+    rc, _ = _create(descs, 1)
+    assert rc == 1 and b"at least an input layer" in lib.yolo_last_error()
+    rc, _ = _create(None, 0)
+    assert rc == 1
+    with pytest.raises(ValueError):
+        engine.Plan(new_graph(8, 8, 3), dtype="int8")
+    # forward without workspace / weights on a device-free plan
+    g = new_graph(8, 8, 3)
+    g.append(PL.conv2d_bn_act(g[-1].out, 16, 3, 1))
+    p = engine.Plan(g, dtype="fp16", max_batch=2)
+    buf = (C.c_float * 16)()
+    assert lib.yolo_net_forward(p.handle, buf, 3, buf, None) == 1 and b"batch outside" in lib.yolo_last_error()
+    assert lib.yolo_net_forward(p.handle, buf, 1, buf, None) == 5 and b"weights not loaded" in lib.yolo_last_error()
+    assert lib.yolo_net_load_weights(p.handle, buf, 5, buf, 1 << 20) == 1      # misaligned / too small is an ARG error first
+    hd = _hip.HeadDesc()
+    assert lib.yolo_net_set_head(p.handle, C.byref(hd)) == 1
+    assert lib.yolo_decode_scratch_bytes(C.byref(hd), 4, 4096) >= 4 * 4096 * 40
+
+
+def test_detection_head_geometry_roundtrip():
+    net = v3.create_network(np.reshape(cases.COCO_V3_ANCHORS, [-1, 2]), NAMES80, False, input_shape=(416, 416, 3))
+    p = engine.Plan(net, dtype="fp16", max_batch=1)
+    hd = _hip.HeadDesc()
+    _hip.check(p.lib.yolo_net_head_desc(p.handle, C.byref(hd)))
+    assert hd.n_classes == 80 and [hd.n_anchors[i] for i in range(3)] == [3, 3, 3]
+    assert abs(hd.anchors[0][0] - 116 / 32) < 1e-12 and abs(hd.anchors[2][1] - 13 / 8) < 1e-12

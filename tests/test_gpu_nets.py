@@ -1,0 +1,62 @@
+"""GPU: whole networks through the C ABI against the CPU oracle (same synthetic Darknet bytes on
+both sides).  fp32 carries the 1e-4 logit contract; fp16 is bounded against the fp16-storage
+emulation and its distance to the fp32 reference is reported."""
+import numpy as np
+import pytest
+
+from helpers import rel_err, run_hip, to_oracle
+from oracle import cases, forward_ref as FR
+from tensorflow_yolo_amd.net import synth, v2, v3
+
+pytestmark = pytest.mark.gpu
+
+NAMES80 = ["c%d" % i for i in range(80)]
+NAMES20 = NAMES80[:20]
+
+
+def build(kind, size):
+    if kind == "v2":
+        return v2.create_full_network(np.reshape(cases.COCO_V2_ANCHORS, [-1, 2]), NAMES80, False, input_shape=(size, size, 3)), 80
+    if kind == "tiny":
+        return v2.create_tiny_network(np.reshape(cases.VOC_TINY_ANCHORS, [-1, 2]), NAMES20, False, input_shape=(size, size, 3)), 20
+    return v3.create_network(np.reshape(cases.COCO_V3_ANCHORS, [-1, 2]), NAMES80, False, input_shape=(size, size, 3)), 80
+
+
+@pytest.mark.parametrize("kind,size,batch", [("v2", 416, 2), ("v2", 160, 3), ("tiny", 416, 2), ("v3", 160, 2), ("v3", 416, 1)])
+def test_logits_fp32_within_1e4(kind, size, batch):
+    net, nc = build(kind, size)
+    w = synth.darknet_stream(net, seed=5, num_classes=nc)
+    x = synth.synthetic_input(batch, size, size, 3, seed=6)
+    want = FR.forward(to_oracle(net), w, x)
+    got, eng = run_hip(net, w, x, "fp32")
+    assert got.shape == want.shape
+    err = float(np.max(np.abs(got.astype(np.float64) - want)))
+    print("%s-%d b%d fp32: max|logit| %.3f  max abs err %.3e  kernels %d" % (kind, size, batch, np.abs(want).max(), err, eng.num_kernels))
+    assert err <= 1e-4 * max(1.0, float(np.abs(want).max())), err
+
+
+@pytest.mark.parametrize("kind,size,batch", [("v2", 416, 2), ("tiny", 416, 2), ("v3", 160, 2), ("v3", 320, 1)])
+def test_logits_fp16_bounded(kind, size, batch):
+    net, nc = build(kind, size)
+    w = synth.darknet_stream(net, seed=5, num_classes=nc)
+    x = synth.synthetic_input(batch, size, size, 3, seed=6)
+    L = to_oracle(net)
+    want16 = FR.forward(L, w, x, storage="fp16")
+    want32 = FR.forward(L, w, x)
+    got, eng = run_hip(net, w, x, "fp16")
+    e16 = rel_err(got, want16)
+    e32 = float(np.max(np.abs(got.astype(np.float64) - want32)))
+    print("%s-%d b%d fp16: vs fp16-emulating oracle rel %.2e; vs fp32 reference max abs %.3e (max|logit| %.2f)"
+          % (kind, size, batch, e16, e32, np.abs(want32).max()))
+    # fp16 rounding noise decorrelates through tens of layers; the emulation differs only in fp32 summation order
+    assert e16 <= 2e-2, e16
+    assert e32 <= 0.15 * max(1.0, float(np.abs(want32).max())), e32
+
+
+def test_known_answer_sizes_from_the_library():
+    from tensorflow_yolo_amd.net import engine
+    for kind, size, wc, oc, gf in (("v2", 416, 50983561, 13 * 13 * 425, 29.464), ("v3", 608, 62001757, 22743 * 85, 140.692),
+                                   ("tiny", 416, 15867885, 13 * 13 * 125, 6.971)):
+        net, _ = build(kind, size)
+        p = engine.Plan(net, dtype="fp16", max_batch=2)
+        assert p.weight_count == wc and p.output_count == oc and round(p.flops_per_image / 1e9, 3) == gf

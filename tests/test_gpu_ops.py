@@ -1,0 +1,195 @@
+"""GPU: every kernel / fusion of the HIP path against the CPU oracle, through the C ABI.
+
+fp32 path: compared with the oracle's fp32 arithmetic (the reference's), tolerance 1e-4 of the
+tensor's magnitude (north_star: logits within 1e-4).
+fp16 path: compared with the oracle run with the same fp16 storage roundings (tight bound:
+2 fp16 ulps of the tensor magnitude) -- fp16 storage vs the fp32 reference is reported by
+test_gpu_nets.py.
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+from helpers import new_graph, rel_err, run_hip, to_oracle
+from oracle import forward_ref as FR, topology as T
+from tensorflow_yolo_amd.net import layers as PL, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32": 1e-4, "fp16": 2.5e-3}
+
+
+def oracle_out(net, w, x, dtype, keep=None):
+    L = to_oracle(net)
+    return FR.forward(L, w, x, keep=keep, storage="fp16" if dtype == "fp16" else None)
+
+
+def check_graph(net, x, dtype, seed=0, read=(), max_batch=None):
+    w = synth.darknet_stream(net, seed=seed)
+    want, kept = oracle_out(net, w, x, dtype, keep=set(read))
+    got, eng = run_hip(net, w, x, dtype, keep_all=bool(read), max_batch=max_batch)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    errs = {"final": rel_err(got, want)}
+    for i in read:
+        errs[i] = rel_err(eng.read_layer(i, x.shape[0]), kept[i])
+    print(dtype, "kernels=%d" % eng.num_kernels, {k: "%.2e" % v for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if not v <= TOL[dtype]}
+    assert not bad, "relative error above %g: %s\n%s" % (TOL[dtype], bad, eng.describe())
+    return eng
+
+
+CONV_CASES = {
+    # name: (B, H, W, Cin, Cout, k, s, bn, act)
+    "first_3to32": (2, 17, 19, 3, 32, 3, 1, True, "leaky"),
+    "first_3to16_tiny": (2, 16, 16, 3, 16, 3, 1, True, "leaky"),
+    "c16to32": (2, 12, 12, 16, 32, 3, 1, True, "leaky"),
+    "c32to64_s2_odd": (2, 15, 13, 32, 64, 3, 2, True, "leaky"),
+    "c32to64_s1": (1, 20, 20, 32, 64, 3, 1, True, "leaky"),
+    "c64to128": (2, 9, 11, 64, 128, 3, 1, True, "leaky"),
+    "c128to64_1x1": (2, 9, 11, 128, 64, 1, 1, True, "leaky"),
+    "c64to32_1x1": (2, 10, 10, 64, 32, 1, 1, True, "leaky"),
+    "c128to256_s2": (2, 10, 10, 128, 256, 3, 2, True, "leaky"),
+    "c256to512_linear_bias": (1, 7, 7, 256, 512, 3, 1, False, "linear"),
+    "c768_1x1": (1, 6, 6, 768, 256, 1, 1, True, "leaky"),
+    "c384_1x1": (1, 6, 6, 384, 128, 1, 1, True, "leaky"),
+    "m_tail_3069": (3, 33, 31, 64, 64, 3, 1, True, "leaky"),
+    "k_long_1280": (1, 13, 13, 1280, 256, 3, 1, True, "leaky"),
+}
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("name", sorted(CONV_CASES))
+def test_conv_mid_and_pool(name, dtype):
+    """conv in the middle of a graph (T-typed vector stores) followed by a stride-1 max-pool."""
+    B, H, W, cin, cout, k, s, bn, act = CONV_CASES[name]
+    g = new_graph(H, W, cin)
+    g.append(PL.conv2d_bn_act(g[-1].out, cout, k, s, use_batch_normalization=bn, activation_fn=act))
+    g.append(PL.max_pool2d(g[-1].out, 2, stride=1))
+    x = synth.synthetic_input(B, H, W, cin, seed=3) * 2 - 1
+    check_graph(g, x, dtype, seed=zlib.crc32(name.encode()) % 1000, read=(1,))
+
+
+HEAD_CASES = {
+    "head255": (2, 5, 5, 256, 255),
+    "head425": (2, 13, 13, 1024, 425),
+    "head125": (1, 13, 13, 1024, 125),
+    "head18_tower": (1, 13, 13, 1024, 18),
+    "head_vec_256": (2, 6, 6, 128, 256),
+}
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("name", sorted(HEAD_CASES))
+def test_conv_last_writes_float32(name, dtype):
+    """the last conv (linear, bias, no BN) writes float32 logits straight to the caller's tensor"""
+    B, H, W, cin, cout = HEAD_CASES[name]
+    g = new_graph(H, W, cin)
+    g.append(PL.conv2d_bn_act(g[-1].out, cout, 1, 1, use_batch_normalization=False, activation_fn="linear"))
+    x = synth.synthetic_input(B, H, W, cin, seed=4) * 2 - 1
+    check_graph(g, x, dtype, seed=7)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_residual_blocks_fused(dtype):
+    g = new_graph(16, 16, 3)
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 3, 2))
+    for _ in range(2):
+        g.append(PL.conv2d_bn_act(g[-1].out, 32, 1))
+        g.append(PL.conv2d_bn_act(g[-1].out, 64, 3))
+        g.append(PL.shortcut(g[-1].out, g[-3].out))
+    x = synth.synthetic_input(2, 16, 16, 3, seed=5)
+    eng = check_graph(g, x, dtype, read=(2, 5))
+    assert eng.num_kernels == 1 + 6          # prep + convs only: the adds are epilogues
+    assert "fused: +shortcut" in eng.describe()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_upsample_concat_fused(dtype):
+    g = new_graph(8, 8, 64)
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 3, 1))                  # 1  skip source (writes a concat slice)
+    g.append(PL.conv2d_bn_act(g[-1].out, 128, 3, 2))                 # 2  4x4
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 1, 1))                  # 3
+    g.append(PL.upsample(g[-1].out, 2))                              # 4  fused into 3
+    g.append(PL.route([g[-1].out, g[1].out]))                        # 5  [up, skip] = 128 ch
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 1, 1))                  # 6
+    x = synth.synthetic_input(2, 8, 8, 64, seed=6) * 2 - 1
+    eng = check_graph(g, x, dtype, read=(4, 5))
+    d = eng.describe()
+    assert eng.num_kernels == 5 and "fused: upsample x2" in d and "concat slice" in d
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_reorg_concat_fused_v2_style(dtype):
+    g = new_graph(8, 8, 64)
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 3, 1))                  # 1  8x8x64
+    g.append(PL.max_pool2d(g[-1].out, 2, 2))                         # 2  4x4
+    g.append(PL.conv2d_bn_act(g[-1].out, 128, 3, 1))                 # 3  4x4x128 -> concat slice
+    g.append(PL.route([g[1].out]))                                   # 4  alias of 1
+    g.append(PL.conv2d_bn_act(g[-1].out, 16, 1, 1))                  # 5  8x8x16
+    g.append(PL.reorg(g[-1].out, 2))                                 # 6  4x4x64, fused into 5
+    g.append(PL.route([g[-1].out, g[3].out]))                        # 7  192 ch
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 3, 1))                  # 8
+    x = synth.synthetic_input(2, 8, 8, 64, seed=7) * 2 - 1
+    eng = check_graph(g, x, dtype, read=(6, 7))
+    assert "fused: reorg x2" in eng.describe()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_standalone_fallback_kernels(dtype):
+    """graphs where the fusions do not apply: generic strided element-wise kernels take over"""
+    g = new_graph(8, 8, 16)
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))                  # 1  two consumers -> shortcut not fusable
+    g.append(PL.max_pool2d(g[-1].out, 2, 1))                         # 2
+    g.append(PL.shortcut(g[1].out, g[2].out))                        # 3  standalone add
+    g.append(PL.max_pool2d(g[-1].out, 2, 2))                         # 4  4x4x32
+    g.append(PL.upsample(g[-1].out, 2))                              # 5  standalone upsample (of a pool)
+    g.append(PL.reorg(g[3].out, 2))                                  # 6  standalone reorg 4x4x128
+    g.append(PL.route([g[4].out, g[6].out]))                         # 7  4x4x160
+    g.append(PL.route([g[7].out, g[4].out]))                         # 8  nested concat -> copies, 192 ch
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 1, 1))                  # 9
+    g.append(PL.route([g[5].out, g[3].out]))                         # 10 8x8x64 last layer = route
+    x = synth.synthetic_input(2, 8, 8, 16, seed=8) * 2 - 1
+    check_graph(g, x, dtype, read=(3, 5, 6, 8, 9))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_maxpool_odd_and_same(dtype):
+    g = new_graph(7, 9, 3)
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))
+    g.append(PL.max_pool2d(g[-1].out, 2, 2))                         # odd dims: zero pad takes part
+    g.append(PL.max_pool2d(g[-1].out, 2, 1))
+    g.append(PL.max_pool2d(g[-1].out, 2, 2))
+    x = synth.synthetic_input(3, 7, 9, 3, seed=9)
+    check_graph(g, x, dtype, read=(2, 3))
+
+
+def test_variable_batch_below_max_batch():
+    g = new_graph(12, 12, 3)
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 3, 2))
+    g.append(PL.conv2d_bn_act(g[-1].out, 18, 1, 1, use_batch_normalization=False, activation_fn="linear"))
+    w = synth.darknet_stream(g, seed=1)
+    x = synth.synthetic_input(4, 12, 12, 3, seed=10)
+    from tensorflow_yolo_amd.net import engine
+    eng = engine.HipNetwork(g, dtype="fp32", max_batch=4)
+    eng.load_weights(w)
+    full = eng.forward(x).cpu().numpy()
+    for b in (1, 3):
+        part = eng.forward(x[:b]).cpu().numpy()
+        assert np.array_equal(part, full[:b])
+    with pytest.raises(ValueError):
+        eng.forward(np.concatenate([x, x]))
+
+
+def test_errors_are_reported():
+    from tensorflow_yolo_amd import _hip
+    from tensorflow_yolo_amd.net import engine
+    g = new_graph(8, 8, 3)
+    g.append(PL.conv2d_bn_act(g[-1].out, 16, 3, 1))
+    eng = engine.HipNetwork(g, dtype="fp16", max_batch=1)
+    with pytest.raises(_hip.YoloHipError, match="weights not loaded"):
+        eng.forward(synth.synthetic_input(1, 8, 8, 3))
+    with pytest.raises(_hip.YoloHipError, match="weight stream holds"):
+        eng.load_weights(np.zeros(5, np.float32))

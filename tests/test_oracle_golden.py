@@ -1,0 +1,68 @@
+"""CPU: the oracle's decode + NMS restatement against the committed outputs of the REFERENCE's own
+functions (tests/golden/*.npz, produced by oracle/gen_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+from oracle import cases, decode_ref
+
+
+def _load(name):
+    g = np.load(os.path.join(GOLDEN, "decode_%s.npz" % name))
+    meta = json.loads(str(g["meta"]))
+    return g, meta
+
+
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+def test_decode_matches_reference(name):
+    c = cases.CASES[name]
+    g, meta = _load(name)
+    assert meta["source"] == "reference functions"
+    head = cases.make_head(name)
+    for nms in (False, True):
+        if c["version"] == 2:
+            mine = decode_ref.find_bounding_boxes_v2(head, c["threshold"], c["iou"], c["anchors"], c["classes"], nms=nms)
+        else:
+            sc = decode_ref.v3_scales(c["anchors"], (c["input"], c["input"]))
+            mine = decode_ref.find_bounding_boxes_v3(head, c["threshold"], c["iou"], sc, nms=nms)
+        for i in range(c["batch"]):
+            want = g[("post%d" if nms else "pre%d") % i]
+            got = decode_ref.boxes_to_array(mine[i])
+            assert got.shape == want.shape
+            if len(want):
+                assert np.array_equal(got[:, 4], want[:, 4])                  # class ids, order
+                assert np.allclose(got, want, rtol=0, atol=1e-6)
+
+
+def test_fixture_margins():
+    """The fixtures must not sit on a decision boundary: no candidate within 1e-5 of the score
+    threshold (so float32 exp rounding on another platform cannot flip a box)."""
+    for name, c in cases.CASES.items():
+        g, _ = _load(name)
+        for i in range(c["batch"]):
+            pre = g["pre%d" % i]
+            if len(pre):
+                assert np.min(np.abs(pre[:, 5] - c["threshold"])) > 1e-5, name
+
+
+@pytest.mark.parametrize("name", sorted(cases.NMS_CASES))
+def test_nms_cases_match_reference(name):
+    g = np.load(os.path.join(GOLDEN, "nms_cases.npz"))
+    boxes, thr = cases.NMS_CASES[name]
+    bb = [decode_ref.Box(np.float32(b[0]), np.float32(b[1]), np.float64(b[2]), np.float64(b[3]), b[4], np.float32(b[5]))
+          for b in boxes]
+    kept = decode_ref.boxes_to_array(decode_ref.non_maximum_suppression(bb, thr))
+    assert kept.shape == g[name].shape
+    assert np.allclose(kept, g[name], rtol=0, atol=1e-7)
+
+
+def test_engineered_semantics():
+    g = np.load(os.path.join(GOLDEN, "nms_cases.npz"))
+    assert len(g["iou_exactly_at_threshold"]) == 2          # iou == thr suppresses (>=)
+    assert len(g["iou_just_below_threshold"]) == 2          # iou < thr keeps both
+    assert [int(c) for c in g["equal_prob_keeps_scan_order"][:, 4]] == [3, 4, 6]   # stable order, 5 suppressed by 3
+    assert len(g["zero_area_union_floor"]) == 2             # 0/1e-8 = 0 < thr
+    assert len(g["empty"]) == 0
