@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the YOLO TEST-mode hot path (conv forward + head decode + NMS)
+on N MI355X GPUs of one node, one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload v3-608-b32-fp16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one synthetic batch resident in HBM: float32 NHWC input ->
+libyolo_hip detect (prep + 75 fused convs + decode + NMS) [-> RCCL all-gather of the fixed-size box
+records when N > 1].  Images shard over ranks (weak scaling: every rank runs the full per-GPU batch).
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  "roofline":     dominant kernel family (the N128 implicit-GEMM conv): algorithmic FLOPs of its launches
+                  / their device time measured with hipEvents on the launch stream (instrumented steps
+                  run right after the timed region; the events add bubbles so they never time `value`)
+  "cpu_baseline": the CPU oracle (torch-CPU restatement of the reference's TF path + NumPy decode/NMS,
+                  kind "port") timed on the host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (model, input, per-GPU batch, dtype)            BASELINE.json configs[2] / [1] / [4] / [0]
+    "v3-608-b32-fp16": ("v3", 608, 32, "fp16"),
+    "v2-416-b16-fp16": ("v2", 416, 16, "fp16"),
+    "tiny-v2-voc-416-b64-fp32": ("v2-tiny", 416, 64, "fp32"),
+    "v2-416-b1-fp32": ("v2", 416, 1, "fp32"),
+    "v3-416-b32-fp16": ("v3", 416, 32, "fp16"),
+}
+PEAK = {"fp16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s, MI355X_MICROARCH.md "Chip-level parameters"
+COCO_V2 = [0.57273, 0.677385, 1.87446, 2.06253, 3.33843, 5.47434, 7.88282, 3.52778, 9.77052, 9.16828]
+VOC_TINY = [1.08, 1.19, 3.42, 4.41, 6.63, 11.38, 9.42, 5.11, 16.62, 10.52]
+COCO_V3 = [10, 13, 16, 30, 33, 23, 30, 61, 62, 45, 59, 119, 116, 90, 156, 198, 373, 326]
+
+
+def make_model(kind, size, batch, dtype, seed=0):
+    from tensorflow_yolo_amd import YoloV2, YoloV2Tiny, YoloV3
+    from tensorflow_yolo_amd.net import synth
+    cls, anchors, ncls = {"v3": (YoloV3, COCO_V3, 80), "v2": (YoloV2, COCO_V2, 80), "v2-tiny": (YoloV2Tiny, VOC_TINY, 20)}[kind]
+    names = ["c%d" % i for i in range(ncls)]
+    model = cls()
+    net = cls.create_network(np.reshape(anchors, [-1, 2]), names, False, input_shape=(size, size, 3))
+    hg, frac = synth.HEAD_DEFAULTS[kind]
+    w = synth.darknet_stream(net, seed=seed, num_classes=ncls, head_gain=hg, obj_bias=0.0)
+    model.build(anchors, names, (size, size, 3), dtype=dtype, max_batch=batch, weights=w)
+    # data-dependent objectness prior (uses the product's own forward): a realistic handful of candidates
+    w = synth.calibrate_model(model, synth.synthetic_input(min(batch, 2), size, size, 3, seed=999), frac)
+    return model, w, anchors, ncls
+
+
+def cpu_baseline(kind, size, w, anchors, ncls, budget_s=20.0):
+    """Oracle forward + decode + NMS on the host cores, bounded sample (never the thing shipped)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import to_oracle
+    from oracle import decode_ref, forward_ref
+    from tensorflow_yolo_amd import YoloV2, YoloV2Tiny, YoloV3
+    from tensorflow_yolo_amd.net import synth
+    cls = {"v3": YoloV3, "v2": YoloV2, "v2-tiny": YoloV2Tiny}[kind]
+    names = ["c%d" % i for i in range(ncls)]
+    net = cls.create_network(np.reshape(anchors, [-1, 2]), names, False, input_shape=(size, size, 3))
+    L = to_oracle(net)
+    Wd = forward_ref.parse_darknet_weights(L, w)
+    cores = torch.get_num_threads()
+    chunk = 2
+    x = synth.synthetic_input(chunk, size, size, 3, seed=123)
+
+    def one():
+        logits = forward_ref.forward(L, Wd, x)
+        if kind == "v3":
+            sc = decode_ref.v3_scales(anchors, (size, size))
+            decode_ref.find_bounding_boxes_v3(logits, 0.5, 0.6, sc)
+        else:
+            decode_ref.find_bounding_boxes_v2(logits, 0.5, 0.6, anchors, ncls)
+
+    one()                                   # warm-up (thread pool, allocator)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += chunk
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 64:
+            break
+    return {"value": round(n / dt, 3), "unit": "images/sec", "cores": int(cores), "kind": "port",
+            "sample": "%d images %dx%d, CPU oracle (torch-CPU fp32 restatement of the reference's TF path + NumPy decode/NMS), "
+                      "%.1f s" % (n, size, size, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="v3-608-b32-fp16", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--threshold", type=float, default=0.5)
+    ap.add_argument("--iou-threshold", type=float, default=0.6)
+    ap.add_argument("--dump-kernels", default=None, help="write the per-kernel timing table (JSON) here")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    kind, size, batch, dtype = WORKLOADS[args.workload]
+    model, w, anchors, ncls = make_model(kind, size, batch, dtype)
+    eng = model.net.engine
+    from tensorflow_yolo_amd.net import synth
+    # two different resident input batches, alternated, so no step re-reads the previous step's input
+    xs = [torch.from_numpy(synth.synthetic_input(batch, size, size, 3, seed=1000 + 17 * rank + i)).to(dev) for i in range(2)]
+    gathered = None
+    if world > 1:
+        gathered = torch.empty((world * batch, eng.max_boxes, 6), dtype=torch.float32, device=dev)
+        gcounts = torch.empty((world * batch,), dtype=torch.int32, device=dev)
+
+    def step(i):
+        boxes, counts, status = eng.detect(xs[i & 1], args.threshold, args.iou_threshold)
+        if world > 1:       # the only exchange of the path: fixed-size box records, rank order == image order
+            dist.all_gather_into_tensor(gathered, boxes.contiguous())
+            dist.all_gather_into_tensor(gcounts, counts.contiguous())
+        return boxes, counts, status
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        boxes, counts, status = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = status.cpu().numpy()
+    nboxes = counts.cpu().numpy()
+    if (st & 1).any():
+        raise RuntimeError("candidate overflow during the benchmark: result would not match the reference")
+
+    out = None
+    if rank == 0:
+        total_images = args.steps * batch * world
+        value = total_images / elapsed
+        # ---- roofline of the dominant kernel family, instrumented steps (hipEvents on the launch stream)
+        infos = eng.kernel_infos()
+        reps = max(3, min(10, args.steps))
+        ms = np.zeros(eng.num_kernels, dtype=np.float64)
+        for r in range(reps):
+            ms += eng.forward_timed(xs[r & 1])
+        ms /= reps
+        fam = {}
+        for k, ki in enumerate(infos):
+            f = fam.setdefault(ki.name.decode(), {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            f["launches"] += 1
+            f["ms"] += float(ms[k])
+            f["flops"] += ki.flops * batch
+            f["bytes"] += ki.bytes * batch + ki.weight_bytes
+        dom = max(fam, key=lambda n: fam[n]["ms"])
+        d = fam[dom]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK[dtype], "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK[dtype], 4), "traffic": None,
+                "launches_per_step": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 5),
+                "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
+                "algorithmic_mb_per_launch": round(d["bytes"] / d["launches"] / 1e6, 3),
+                "forward_ms_sum_of_kernels": round(float(ms.sum()), 4),
+                "whole_forward_tflops": round(eng.flops_per_image * batch / (float(ms.sum()) * 1e-3) / 1e12, 2)}
+        tj = os.path.join(ROOT, "profiles", "traffic.json")      # HBM bytes per launch from rocprofv3 --pmc passes, if recorded
+        if os.path.exists(tj):
+            try:
+                roof["traffic"] = json.load(open(tj)).get(args.workload, {}).get(dom)
+            except Exception:
+                pass
+        if args.dump_kernels:
+            rows = [{"kernel": k, "name": ki.name.decode(), "layer": ki.layer, "k": ki.ksize, "s": ki.stride, "cin": ki.cin,
+                     "cout": ki.cout, "out_hw": [ki.out_h, ki.out_w], "ms": round(float(ms[k]), 5),
+                     "tflops": round(ki.flops * batch / (ms[k] * 1e-3) / 1e12, 2) if ms[k] > 0 else 0.0,
+                     "gbps": round((ki.bytes * batch + ki.weight_bytes) / (ms[k] * 1e-3) / 1e9, 1) if ms[k] > 0 else 0.0}
+                    for k, ki in enumerate(infos)]
+            with open(args.dump_kernels, "w") as f:
+                json.dump({"workload": args.workload, "families": fam, "kernels": rows}, f, indent=1)
+        out = {
+            "metric": "images/sec at 1/2/4/8 MI355X + post-NMS box-set match vs CPU ref",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16" if dtype == "fp16" else "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "model": kind, "input": [size, size, 3], "batch_per_gpu": batch,
+                       "global_batch": batch * world, "weights": "seeded synthetic Darknet stream (random-init)",
+                       "threshold": args.threshold, "iou_threshold": args.iou_threshold,
+                       "sharding": "images over ranks; all-gather of box records only" if world > 1 else "single GPU",
+                       "boxes_per_image_last_step": round(float(nboxes.mean()), 1),
+                       "forward_gflop_per_image": round(eng.flops_per_image / 1e9, 3)},
+            "roofline": roof,
+            "forward_frac_of_mfma_peak": round(eng.flops_per_image * total_images / elapsed / 1e12 / PEAK[dtype], 4),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(kind, size, w, anchors, ncls)
+        else:
+            out["cpu_baseline"] = None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -42,10 +42,12 @@ __device__ __forceinline__ float4v mma_chunk<_Float16>(const uint4v &a, const ui
 // k = {e, 4+e, 8+e, 12+e}: all 16 k of the 4 chunks (exact fp32 FMA chain).
 template <>
 __device__ __forceinline__ float4v mma_chunk<float>(const uint4v &a, const uint4v &b, float4v c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), c, 0, 0, 0);
+    // (element-wise __builtin_bit_cast(float, a.x) miscompiles to element 0 for all four: copy out)
+    float af[4], bf[4];
+    __builtin_memcpy(af, &a, 16);
+    __builtin_memcpy(bf, &b, 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], c, 0, 0, 0);
     return c;
 }
 
