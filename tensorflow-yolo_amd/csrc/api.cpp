@@ -205,7 +205,24 @@ int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, h
                 p.res_img_stride = k.in2.img_stride;
                 p.vec_res = (k.cout % ch == 0) && (k.in2.ld % epc == 0) && (k.in2.coff % epc == 0) && (k.in2.img_stride % epc == 0);
             }
-            e = launch_conv(p, dtype, k.cfg, k.perchunk != 0, s);
+            int tile = 0;
+            if (dtype == YOLO_DTYPE_F16 && !k.perchunk && k.cfg == CFG_N128) tile = choose_dma_cfg(p.M, k.cout);
+            e = tile ? launch_conv_dma(p, tile, s) : launch_conv(p, dtype, k.cfg, k.perchunk != 0, s);
+            break;
+        }
+        case K_FIRST: {
+            FirstParams p;
+            p.in = in_dev;
+            p.wgt = reinterpret_cast<const float *>(net->dev_weights + k.w_off);
+            p.bias = reinterpret_cast<const float *>(net->dev_weights + k.b_off);
+            p.out = P.view_ptr(k.out);
+            p.H = k.in.H; p.W = k.in.W; p.Cout = k.cout; p.out_ld = k.out.ld; p.leaky = k.leaky;
+            p.round_half = dtype == YOLO_DTYPE_F16;
+            p.out_img_stride = k.out.img_stride;
+            p.total = (long long)batch * k.in.H * k.in.W;
+            if (k.out.ld % epc || (k.out.base + k.out.coff) % epc || k.out.img_stride % epc)
+                return fail(YOLO_ERR_PLAN, "first-layer kernel needs a 16-byte aligned output view");
+            e = launch_first(p, dtype, s);
             break;
         }
         case K_POOL: {
@@ -333,8 +350,22 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         out->flops = 2.0 * li.H * li.W * k.cout * k.ksize * k.ksize * k.cin;
         out->bytes = (double)k.in.H * k.in.W * k.cin * net->esize + elems(k.out) * esz(k.out) + (k.has_res ? elems(k.in2) * net->esize : 0.0);
         out->weight_bytes = (double)k.cout * k.ksize * k.ksize * k.cin * net->esize + 4.0 * k.cout;
-        snprintf(out->name, sizeof out->name, "conv_igemm<%s,N%d,%s>", t, k.cfg == CFG_N128 ? 128 : k.cfg == CFG_N64 ? 64 : 32,
-                 k.perchunk ? "perchunk" : "uniform");
+        int tile = 0;       // which kernel runs at max_batch (bench.py runs at max_batch)
+        if (net->opt.dtype == YOLO_DTYPE_F16 && !k.perchunk && k.cfg == CFG_N128)
+            tile = choose_dma_cfg(net->opt.max_batch * li.H * li.W, k.cout);
+        if (tile) {
+            out->variant = 8 + tile;
+            snprintf(out->name, sizeof out->name, "conv_igemm_dma<f16,%s>", dma_cfg_name(tile));
+        } else {
+            snprintf(out->name, sizeof out->name, "conv_igemm<%s,N%d,%s>", t, k.cfg == CFG_N128 ? 128 : k.cfg == CFG_N64 ? 64 : 32,
+                     k.perchunk ? "perchunk" : "uniform");
+        }
+    } else if (k.kind == K_FIRST) {
+        out->ksize = 3; out->stride = 1; out->cin = 3; out->cout = k.cout; out->out_h = k.out.H; out->out_w = k.out.W;
+        out->flops = 2.0 * k.out.H * k.out.W * k.cout * 27;
+        out->bytes = (double)k.in.H * k.in.W * 3 * 4 + elems(k.out) * esz(k.out);
+        out->weight_bytes = 28.0 * k.cout * 4;
+        snprintf(out->name, sizeof out->name, "conv_first<%s,%d>", t, k.cout);
     } else {
         out->out_h = k.out.H; out->out_w = k.out.W; out->cout = k.out.C; out->cin = k.in.C;
         out->bytes = elems(k.in) * (k.in.f32 ? 4.0 : net->esize) + elems(k.out) * esz(k.out) + (k.has_res ? elems(k.in2) * net->esize : 0.0);

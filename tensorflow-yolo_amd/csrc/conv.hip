@@ -20,38 +20,11 @@
 //     staging writes.
 //   * pipeline: global loads of tile t+1 are issued before the MFMAs of tile t and written to the
 //     other LDS buffer after them; one barrier per K tile.
-#include "yolo_internal.h"
+#include "conv_common.h"
 
 namespace yolo {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float float4v __attribute__((ext_vector_type(4)));
-typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
-
-#define INVALID_OFF 0x80000000u
-
-template <typename T>
-__device__ __forceinline__ float4v mma_chunk(const uint4v &a, const uint4v &b, float4v c);
-
-template <>
-__device__ __forceinline__ float4v mma_chunk<_Float16>(const uint4v &a, const uint4v &b, float4v c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
-}
-
-// fp32 operands: element e of every lane's chunk feeds MFMA e, so the four 16x16x4 steps cover
-// k = {e, 4+e, 8+e, 12+e}: all 16 k of the 4 chunks (exact fp32 FMA chain).
-template <>
-__device__ __forceinline__ float4v mma_chunk<float>(const uint4v &a, const uint4v &b, float4v c) {
-    // (element-wise __builtin_bit_cast(float, a.x) miscompiles to element 0 for all four: copy out)
-    float af[4], bf[4];
-    __builtin_memcpy(af, &a, 16);
-    __builtin_memcpy(bf, &b, 16);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], c, 0, 0, 0);
-    return c;
-}
-
-template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+#define INVALID_OFF YOLO_INVALID_OFF
 
 // WM x WN waves; a wave owns TM*16 couts x TP*16 pixels.
 template <typename T, int WM, int WN, int TM, int TP, bool PERCHUNK>
@@ -72,13 +45,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    // XCD-aware bijective remap: the 8 XCDs get contiguous ranges of (pixel-tile, cout-tile) so the
-    // cout tiles of one pixel tile run back to back on one XCD and share its L2 (speed only).
-    int bid = blockIdx.x;
-    {
-        const int q = p.n_blocks >> 3, r = p.n_blocks & 7, x = bid & 7, y = bid >> 3;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
-    }
+    const int bid = xcd_remap(blockIdx.x, p.n_blocks);
     const int nt = bid % p.n_tiles_n;
     const int mt = bid / p.n_tiles_n;
     const int n0 = nt * NA;
@@ -197,90 +164,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: bias, leaky, residual, store --------------------------------------------
-    const int cbase = n0 + wm * (TM * 16) + fq * CH;    // first cout of this lane
-    if (cbase >= p.Cout) return;
-    float bias[CH];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) bias[i] = p.bias[cbase + i];      // bias is padded to 128 couts
-    const int nvalid = p.Cout - cbase < CH ? p.Cout - cbase : CH;
-
-#pragma unroll
-    for (int b = 0; b < TP; ++b) {
-        const int m = m0 + wn * (TP * 16) + b * 16 + fr;
-        if (m >= p.M) continue;
-        const int n = m / p.HoWo;
-        const int rem = m - n * p.HoWo;
-        float v[CH];
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 * a + j] = acc[a][b][j] + bias[4 * a + j];
-        if (p.leaky) {
-#pragma unroll
-            for (int i = 0; i < CH; ++i) v[i] = fmaxf(0.1f * v[i], v[i]);       // layers.py:6,51
-        }
-        if (p.has_res) {        // shortcut: plain add, no activation afterwards (layers.py:102)
-            const T *rp = reinterpret_cast<const T *>(p.res) + (long long)n * p.res_img_stride + (long long)rem * p.res_ld + cbase;
-            if (p.vec_res) {
-#pragma unroll
-                for (int q = 0; q < CH / EPC; ++q) {
-                    const uint4v u = *reinterpret_cast<const uint4v *>(rp + q * EPC);
-                    T t[EPC];
-                    __builtin_memcpy(t, &u, 16);
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) v[q * EPC + e] += to_f32<T>(t[e]);
-                }
-            } else {
-                for (int i = 0; i < nvalid; ++i) v[i] += to_f32<T>(rp[i]);
-            }
-        }
-        // output position(s)
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        long long off[4];
-        int npos = 1;
-        if (p.outmode == OUT_NORMAL) {
-            off[0] = (long long)n * p.out_img_stride + (long long)rem * p.out_ld + cbase;
-        } else if (p.outmode == OUT_UP2) {      // out[2oy+dy][2ox+dx] = v  (layers.py:115)
-            const long long W2 = 2LL * p.Wo;
-            const long long base = (long long)n * p.out_img_stride + ((2LL * oy) * W2 + 2LL * ox) * p.out_ld + cbase;
-            off[0] = base; off[1] = base + p.out_ld; off[2] = base + W2 * p.out_ld; off[3] = base + (W2 + 1) * p.out_ld;
-            npos = 4;
-        } else {                                // reorg: block-major space-to-depth (layers.py:92-96)
-            const int W2 = p.Wo >> 1;
-            off[0] = (long long)n * p.out_img_stride + ((long long)(oy >> 1) * W2 + (ox >> 1)) * p.out_ld
-                     + ((oy & 1) * 2 + (ox & 1)) * p.Cout + cbase;
-        }
-        if (p.out_f32) {
-            float *op = reinterpret_cast<float *>(p.out);
-            for (int q = 0; q < npos; ++q) {
-                if (p.vec_out) {
-#pragma unroll
-                    for (int i = 0; i < CH / 4; ++i)
-                        *reinterpret_cast<float4v *>(op + off[q] + 4 * i) = float4v{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
-                } else {
-                    for (int i = 0; i < nvalid; ++i) op[off[q] + i] = v[i];
-                }
-            }
-        } else {
-            T *op = reinterpret_cast<T *>(p.out);
-            T t[CH];
-#pragma unroll
-            for (int i = 0; i < CH; ++i) t[i] = (T)v[i];
-            for (int q = 0; q < npos; ++q) {
-                if (p.vec_out) {
-#pragma unroll
-                    for (int i = 0; i < CH / EPC; ++i) {
-                        uint4v u;
-                        __builtin_memcpy(&u, t + i * EPC, 16);
-                        *reinterpret_cast<uint4v *>(op + off[q] + i * EPC) = u;
-                    }
-                } else {
-                    for (int i = 0; i < nvalid; ++i) op[off[q] + i] = t[i];
-                }
-            }
-        }
-    }
+    // ---- epilogue: bias, leaky, residual, store (conv_common.h) -------------------------------
+    conv_epilogue<T, TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH, m0 + wn * (TP * 16), fr);
 }
 
 template <typename T, bool PC>

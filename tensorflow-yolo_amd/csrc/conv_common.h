@@ -1,0 +1,139 @@
+// Shared device pieces of the implicit-GEMM conv kernels (conv.hip: register-staged 4-wave kernel;
+// conv_dma.hip: LDS-DMA 8-wave kernel): MFMA wrappers and the fused epilogue.
+#pragma once
+#include "yolo_internal.h"
+
+namespace yolo {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+
+#define YOLO_INVALID_OFF 0x80000000u    // >= any buffer size we accept: the range check returns zeros
+
+template <typename T>
+__device__ __forceinline__ float4v mma_chunk(const uint4v &a, const uint4v &b, float4v c);
+
+// one 16-byte chunk per lane = 8 halfs: lane group q = lane>>4 holds k = 8q..8q+7 of the 32-deep step
+template <>
+__device__ __forceinline__ float4v mma_chunk<_Float16>(const uint4v &a, const uint4v &b, float4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+
+// fp32 operands: element e of every lane's chunk feeds MFMA e, so the four 16x16x4 steps cover
+// k = {e, 4+e, 8+e, 12+e}: all 16 k of the 4 chunks (exact fp32 FMA chain).
+template <>
+__device__ __forceinline__ float4v mma_chunk<float>(const uint4v &a, const uint4v &b, float4v c) {
+    // (element-wise __builtin_bit_cast(float, a.x) miscompiles to element 0 for all four: copy out)
+    float af[4], bf[4];
+    __builtin_memcpy(af, &a, 16);
+    __builtin_memcpy(bf, &b, 16);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], c, 0, 0, 0);
+    return c;
+}
+
+// Epilogue of one wave: acc[a][b] is the 16x16 tile (cout tile a, pixel tile b); with the
+// cout <-> LDS-row permutation of the staging code a lane owns CH = 4*TM CONTIGUOUS couts
+// (cbase ..) of pixel (m_wave + 16 b + fr).  bias (folded BN) -> leaky 0.1 (layers.py:6,51) ->
+// + residual (shortcut, layers.py:102: no activation after the add) -> store through the output
+// index map (identity / nearest-upsample x2 layers.py:115 / block-major reorg layers.py:92-96).
+template <typename T, int TM, int TP>
+__device__ __forceinline__ void conv_epilogue(const ConvParams &p, const float4v (&acc)[TM][TP], int cbase, int m_wave, int fr) {
+    constexpr int CH = 4 * TM;
+    constexpr int EPC = 16 / (int)sizeof(T);
+    if (cbase >= p.Cout) return;
+    float bias[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) bias[i] = p.bias[cbase + i];      // bias is padded to 128 couts
+    const int nvalid = p.Cout - cbase < CH ? p.Cout - cbase : CH;
+
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+        const int m = m_wave + b * 16 + fr;
+        if (m >= p.M) continue;
+        const int n = m / p.HoWo;
+        const int rem = m - n * p.HoWo;
+        float v[CH];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * a + j] = acc[a][b][j] + bias[4 * a + j];
+        if (p.leaky) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) v[i] = fmaxf(0.1f * v[i], v[i]);
+        }
+        if (p.has_res) {
+            const T *rp = reinterpret_cast<const T *>(p.res) + (long long)n * p.res_img_stride + (long long)rem * p.res_ld + cbase;
+            if (p.vec_res) {
+#pragma unroll
+                for (int q = 0; q < CH / EPC; ++q) {
+                    const uint4v u = *reinterpret_cast<const uint4v *>(rp + q * EPC);
+                    T t[EPC];
+                    __builtin_memcpy(t, &u, 16);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[q * EPC + e] += (float)t[e];
+                }
+            } else {
+                for (int i = 0; i < nvalid; ++i) v[i] += (float)rp[i];
+            }
+        }
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        long long off[4];
+        int npos = 1;
+        if (p.outmode == OUT_NORMAL) {
+            off[0] = (long long)n * p.out_img_stride + (long long)rem * p.out_ld + cbase;
+        } else if (p.outmode == OUT_UP2) {
+            const long long W2 = 2LL * p.Wo;
+            const long long base = (long long)n * p.out_img_stride + ((2LL * oy) * W2 + 2LL * ox) * p.out_ld + cbase;
+            off[0] = base; off[1] = base + p.out_ld; off[2] = base + W2 * p.out_ld; off[3] = base + (W2 + 1) * p.out_ld;
+            npos = 4;
+        } else {
+            const int W2 = p.Wo >> 1;
+            off[0] = (long long)n * p.out_img_stride + ((long long)(oy >> 1) * W2 + (ox >> 1)) * p.out_ld
+                     + ((oy & 1) * 2 + (ox & 1)) * p.Cout + cbase;
+        }
+        if (p.out_f32) {
+            float *op = reinterpret_cast<float *>(p.out);
+            for (int q = 0; q < npos; ++q) {
+                if (p.vec_out) {
+#pragma unroll
+                    for (int i = 0; i < CH / 4; ++i)
+                        *reinterpret_cast<float4v *>(op + off[q] + 4 * i) = float4v{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+                } else if (nvalid == CH) {
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) op[off[q] + i] = v[i];
+                } else {
+                    for (int i = 0; i < nvalid; ++i) op[off[q] + i] = v[i];
+                }
+            }
+        } else {
+            T *op = reinterpret_cast<T *>(p.out);
+            T t[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) t[i] = (T)v[i];
+            for (int q = 0; q < npos; ++q) {
+                if (p.vec_out) {
+#pragma unroll
+                    for (int i = 0; i < CH / EPC; ++i) {
+                        uint4v u;
+                        __builtin_memcpy(&u, t + i * EPC, 16);
+                        *reinterpret_cast<uint4v *>(op + off[q] + i * EPC) = u;
+                    }
+                } else {
+                    for (int i = 0; i < nvalid; ++i) op[off[q] + i] = t[i];
+                }
+            }
+        }
+    }
+}
+
+// XCD-aware bijective remap of the linear block id: the 8 XCDs (blocks b, b+8, ... share one) get
+// contiguous ranges of (pixel-tile, cout-tile) so the cout tiles of one pixel tile run back to back
+// on one XCD and share its L2.  Speed only: any placement gives the same result.
+__device__ __forceinline__ int xcd_remap(int bid, int n_blocks) {
+    const int q = n_blocks >> 3, r = n_blocks & 7, x = bid & 7, y = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+}
+
+}  // namespace yolo

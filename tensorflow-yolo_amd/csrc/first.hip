@@ -1,0 +1,121 @@
+// First layer: 3x3 stride-1 conv on the 3-channel input (+ folded BN + leaky).  K = 27 is too thin
+// for the implicit-GEMM tiling (the generic kernel spent 1 ms here at 20 TFLOP/s, 11 % of a YOLOv3
+// step) and the layer is bound by its 64-byte-per-pixel output stream, so this is a direct
+// convolution on the vector ALU: one thread = one output pixel x all couts, weights as scalar (SGPR)
+// operands of packed FMAs, output transposed through LDS so each store instruction writes 1 KiB of
+// contiguous NHWC, float32 input read straight from the
+// caller's tensor (this replaces the input cast/pad pass as well: reference net/layers.py:106-109
+// placeholder + :17-67 conv2d_bn_act), coalesced 16-byte NHWC stores.
+// fp16 nets: input and weights are rounded to fp16 first (same operands as the MFMA path), products
+// accumulate in fp32.
+#include "yolo_internal.h"
+
+namespace yolo {
+
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+
+template <typename T, int COUT>
+__global__ void __launch_bounds__(256) conv_first_kernel(const FirstParams p) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int ROWB = COUT * (int)sizeof(T);     // bytes of one output pixel
+    constexpr int NCH = ROWB / 16;                  // 16-byte chunks per pixel
+    constexpr int LSTR = ROWB + 16;                 // padded LDS row: conflict-free ds_write_b128 for 8 consecutive lanes
+    __shared__ __attribute__((aligned(16))) unsigned char stage[4 * 64 * LSTR];
+    // weights/bias are read at wave-uniform addresses through the constant address space: scalar
+    // loads into SGPRs (scalar-cache resident, 3.5 KB) used as the SGPR operand of the packed FMAs
+    typedef const __attribute__((address_space(4))) float cfloat;
+    cfloat *wg = (cfloat *)p.wgt;
+    cfloat *bg = (cfloat *)p.bias;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    unsigned char *mine = stage + wave * (64 * LSTR);
+
+    // one workgroup = 256 consecutive output pixels (n, oy, ox) in NHWC order; p.total = B*H*W
+    const long long px0 = (long long)blockIdx.x * 256 + wave * 64;      // first pixel of this wave
+    const long long pix = px0 + lane;
+    const bool live = pix < p.total;
+    const long long pp = live ? pix : p.total - 1;
+    const int ox = (int)(pp % p.W);
+    const long long t = pp / p.W;
+    const int oy = (int)(t % p.H);
+    const long long n = t / p.H;
+
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = bg[co];
+#pragma unroll 1
+    for (int kh = 0; kh < 3; ++kh) {
+        const int iy = oy - 1 + kh;                         // SAME padding: one zero row/col each side
+        const bool rowok = (unsigned)iy < (unsigned)p.H;
+        const float *rowp = p.in + ((n * p.H + (rowok ? iy : 0)) * (long long)p.W) * 3;
+        float xin[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int ix = ox - 1 + c;
+            const bool ok = rowok && (unsigned)ix < (unsigned)p.W;
+            const int ixc = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);    // always-valid address: load, then select
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                float v = rowp[ixc * 3 + ci];
+                if (p.round_half) v = (float)(_Float16)v;
+                xin[c][ci] = ok ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                cfloat *w = wg + ((kh * 3 + kw) * 3 + ci) * COUT;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(xin[kw][ci], w[co], acc[co]);
+            }
+    }
+    // leaky, convert, transpose through LDS: lane -> its pixel's row; then every store instruction of
+    // the wave writes 1 KiB of contiguous NHWC output (16 pixels x ROWB)
+    T tv[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        float v = acc[co];
+        if (p.leaky) v = fmaxf(0.1f * v, v);
+        tv[co] = (T)v;
+    }
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        uint4v u;
+        __builtin_memcpy(&u, tv + q * EPC, 16);
+        *reinterpret_cast<uint4v *>(mine + lane * LSTR + q * 16) = u;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0): the wave's own LDS writes are done (wave-private tile)
+    __builtin_amdgcn_wave_barrier();
+    T *obase = reinterpret_cast<T *>(p.out);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int idx = k * 64 + lane;          // chunk index inside the wave's 64-pixel tile
+        const int lp = idx / NCH, ch = idx % NCH;
+        const long long gp = px0 + lp;
+        if (gp < p.total) {
+            const uint4v u = *reinterpret_cast<const uint4v *>(mine + lp * LSTR + ch * 16);
+            const long long img = gp / ((long long)p.H * p.W);
+            const long long rem = gp - img * (long long)p.H * p.W;
+            *reinterpret_cast<uint4v *>(obase + img * p.out_img_stride + rem * p.out_ld + ch * EPC) = u;
+        }
+    }
+}
+
+hipError_t launch_first(const FirstParams &p, int dtype, hipStream_t s) {
+    const long long g = (p.total + 255) / 256;      // one workgroup per 256 output pixels
+    if (g < 1 || g > 0x7fffffffLL) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)g), block(256);
+    if (dtype == YOLO_DTYPE_F16) {
+        if (p.Cout == 32) hipLaunchKernelGGL((conv_first_kernel<_Float16, 32>), grid, block, 0, s, p);
+        else if (p.Cout == 16) hipLaunchKernelGGL((conv_first_kernel<_Float16, 16>), grid, block, 0, s, p);
+        else return hipErrorInvalidValue;
+    } else {
+        if (p.Cout == 32) hipLaunchKernelGGL((conv_first_kernel<float, 32>), grid, block, 0, s, p);
+        else if (p.Cout == 16) hipLaunchKernelGGL((conv_first_kernel<float, 16>), grid, block, 0, s, p);
+        else return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace yolo

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -49,6 +50,7 @@ struct Planner {
     struct Copy { int route, src, coff; };
     std::vector<Copy> copies;
     std::vector<int> route_buf;
+    bool first_direct = false;
     std::string err;
 
     Planner(yolo_net *n_) : net(n_), L(n_->layers), n((int)n_->layers.size()) {}
@@ -285,6 +287,17 @@ struct Planner {
             snprintf(nm, sizeof nm, "layer %d: ", i);
             switch (d.op) {
             case YOLO_OP_INPUT: {
+                // first layer 3x3/1 on a 3-channel input with 16|32 filters: the direct kernel of
+                // first.hip reads the caller's float32 tensor itself, so no cast/pad pass is needed
+                first_direct = n > 2 && d.c == 3 && L[1].d.op == YOLO_OP_CONV && L[1].d.src[0] == 0 && L[1].d.ksize == 3 &&
+                               L[1].d.stride == 1 && (L[1].d.filters == 16 || L[1].d.filters == 32) && sole(0, 1) &&
+                               fuse[1].kind == 0 && !has_head[1] && !has_claim[1] && !getenv("YOLO_NO_FIRST_DIRECT");
+                if (first_direct) {
+                    L[i].view = dense_view(BUF_USER_IN, d.h, d.w, d.c, d.c);
+                    L[i].view.f32 = true;
+                    L[i].materialised = true;
+                    break;
+                }
                 int cpad = roundup(d.c, epc);
                 Kernel k;
                 k.kind = K_PREP; k.layer = 0;
@@ -300,6 +313,25 @@ struct Planner {
             case YOLO_OP_CONV: {
                 int s = resolve(d.src[0]);
                 if (!L[s].materialised) return fail(std::string(nm) + "source not materialised");
+                if (i == 1 && first_direct) {
+                    Kernel k;
+                    k.kind = K_FIRST; k.layer = 1; k.src_layer = 1;
+                    k.in = L[0].view;
+                    k.ksize = 3; k.stride = 1; k.cout = d.filters; k.cin = 3; k.cin_s = 3;
+                    k.leaky = d.leaky; k.batch_norm = d.batch_norm;
+                    k.out = out_view_for(1);
+                    if (has_claim[1]) k.note = "-> concat slice";
+                    k.note += " direct conv on the float32 input (no cast/pad pass)";
+                    k.w_src = wsrc;
+                    wsrc += (size_t)d.filters * 27 + (d.batch_norm ? 4 : 1) * (size_t)d.filters;
+                    k.w_off = woff; k.w_bytes = (size_t)27 * d.filters * 4;
+                    k.b_off = roundup_sz(k.w_off + k.w_bytes, 256);
+                    woff = roundup_sz(k.b_off + (size_t)d.filters * 4, 256);
+                    flops += 2.0 * L[i].H * L[i].W * d.filters * 27;
+                    net->kernels.push_back(k);
+                    L[1].view = k.out; L[1].materialised = true;
+                    break;
+                }
                 const View &in = L[s].view;
                 if (in.f32) return fail(std::string(nm) + "conv cannot read a float32 head tensor");
                 int cin = L[s].C;
@@ -548,6 +580,30 @@ int pack_weights(const yolo_net *net, const float *host, size_t n, std::vector<u
     const bool f16 = net->opt.dtype == YOLO_DTYPE_F16;
     const int epc = net->epc;
     for (const Kernel &k : net->kernels) {
+        if (k.kind == K_FIRST) {        // [27 = (kh,kw,cin)][cout] float32 (first.hip)
+            const float *p = host + k.w_src;
+            const float *beta = nullptr, *gamma = nullptr, *mean = nullptr, *var = nullptr, *bias = nullptr;
+            if (k.batch_norm) { beta = p; gamma = p + k.cout; mean = p + 2 * k.cout; var = p + 3 * k.cout; p += 4 * (size_t)k.cout; }
+            else { bias = p; p += k.cout; }
+            float *wdst = reinterpret_cast<float *>(blob.data() + k.w_off);
+            float *bdst = reinterpret_cast<float *>(blob.data() + k.b_off);
+            for (int o = 0; o < k.cout; ++o) {
+                double scale = 1.0;
+                if (k.batch_norm) {
+                    scale = (double)gamma[o] / std::sqrt((double)var[o] + 1e-5);
+                    bdst[o] = (float)((double)beta[o] - (double)mean[o] * scale);
+                } else {
+                    bdst[o] = bias[o];
+                }
+                for (int t = 0; t < 9; ++t)
+                    for (int ci = 0; ci < 3; ++ci) {
+                        float v = (float)((double)p[((size_t)o * 3 + ci) * 9 + t] * scale);
+                        if (f16) v = (float)(_Float16)v;        // same operand rounding as the MFMA path
+                        wdst[(t * 3 + ci) * k.cout + o] = v;
+                    }
+            }
+            continue;
+        }
         if (k.kind != K_CONV) continue;
         const int taps = k.ksize * k.ksize;
         const float *p = host + k.w_src;
@@ -581,7 +637,7 @@ int pack_weights(const yolo_net *net, const float *host, size_t n, std::vector<u
 }
 
 static const char *kind_name(int k) {
-    switch (k) { case K_PREP: return "prep"; case K_CONV: return "conv"; case K_POOL: return "maxpool"; default: return "eltwise"; }
+    switch (k) { case K_PREP: return "prep"; case K_CONV: return "conv"; case K_POOL: return "maxpool"; case K_FIRST: return "conv_first"; default: return "eltwise"; }
 }
 
 std::string describe(const yolo_net *net) {

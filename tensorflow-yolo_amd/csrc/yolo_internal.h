@@ -20,7 +20,7 @@ namespace yolo {
 enum OutMode { OUT_NORMAL = 0, OUT_UP2 = 1, OUT_REORG2 = 2 };
 enum BufId { BUF_NONE = -1, BUF_USER_OUT = -2, BUF_USER_IN = -3 };
 enum ConvCfg { CFG_N128 = 0, CFG_N64 = 1, CFG_N32 = 2 };   // cout-tile width of the block
-enum KernelKind { K_PREP = 0, K_CONV = 1, K_POOL = 2, K_ELTWISE = 3 };
+enum KernelKind { K_PREP = 0, K_CONV = 1, K_POOL = 2, K_ELTWISE = 3, K_FIRST = 4 };
 
 // A strided NHWC view inside a planned buffer.
 struct View {
@@ -69,6 +69,16 @@ struct PrepParams {            // float32 NHWC [B,H,W,C] -> T NHWC [B,H,W,Cpad],
     void *out;
     long long pixels;
     int C, Cpad;
+};
+
+struct FirstParams {           // first layer: 3x3/1 conv on the float32 NHWC3 input, Cout 16|32
+    const float *in;           // [B,H,W,3] float32 (the caller's tensor)
+    const float *wgt;          // [27][Cout] float32, BN folded (rounded through fp16 for fp16 nets)
+    const float *bias;         // [Cout]
+    void *out;                 // T NHWC view
+    int H, W, Cout, out_ld, leaky, round_half;
+    long long out_img_stride;
+    long long total;           // B*H*W output pixels
 };
 
 struct PoolParams {            // net/layers.py:70-81
@@ -126,7 +136,13 @@ struct NmsParams {
 
 // ---- launchers (kernels.hip / detect.hip) ------------------------------------------------
 hipError_t launch_conv(const ConvParams &p, int dtype, int cfg, bool perchunk, hipStream_t s);
+// conv_dma.hip: 8-wave LDS-DMA kernel for the heavy fp16 layers.  choose_dma_cfg returns 0 when the
+// 4-wave kernel of conv.hip should run, else the tile id for launch_conv_dma.
+int choose_dma_cfg(int M, int cout);
+hipError_t launch_conv_dma(const ConvParams &p, int cfg, hipStream_t s);
+const char *dma_cfg_name(int cfg);
 hipError_t launch_prep(const PrepParams &p, int dtype, hipStream_t s);
+hipError_t launch_first(const FirstParams &p, int dtype, hipStream_t s);
 hipError_t launch_pool(const PoolParams &p, int dtype, hipStream_t s);
 hipError_t launch_eltwise(const EltParams &p, int dtype, hipStream_t s);
 hipError_t launch_decode(const DecodeParams &p, int batch, hipStream_t s);

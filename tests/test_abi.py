@@ -43,7 +43,7 @@ def test_plan_yolov3_608():
     p = engine.Plan(net, dtype="fp16", max_batch=32)
     assert p.weight_count == 62001757 and p.output_count == 22743 * 85
     assert round(p.flops_per_image / 1e9, 3) == 140.692
-    assert p.num_kernels == 76                      # prep + 75 convs: every other layer is fused or a view
+    assert p.num_kernels == 75                      # 75 convs (the first reads the f32 input itself): all else fused or a view
     d = p.describe()
     assert d.count("fused: +shortcut") == 23 and d.count("fused: upsample x2") == 2
     assert d.count("head logits") == 3 and d.count("concat slice") == 4
@@ -57,12 +57,12 @@ def test_plan_yolov2_and_tiny():
     net = v2.create_full_network(np.reshape(cases.COCO_V2_ANCHORS, [-1, 2]), NAMES80, False)
     p = engine.Plan(net, dtype="fp32", max_batch=16)
     assert p.weight_count == 50983561 and p.output_count == 13 * 13 * 425
-    assert p.num_kernels == 1 + 23 + 5              # prep, convs, pools; reorg + routes are free
+    assert p.num_kernels == 23 + 5                  # convs, pools; input cast, reorg and routes are free
     d = p.describe()
     assert "fused: reorg x2" in d and d.count("concat slice") == 2
     tiny = v2.create_tiny_network(np.reshape(cases.VOC_TINY_ANCHORS, [-1, 2]), NAMES80[:20], False)
     pt = engine.Plan(tiny, dtype="fp32", max_batch=64)
-    assert pt.weight_count == 15867885 and pt.num_kernels == 1 + 9 + 6
+    assert pt.weight_count == 15867885 and pt.num_kernels == 9 + 6
 
 
 def test_fallback_graph_plans():
