@@ -135,6 +135,10 @@ int yolo_net_bind_workspace(yolo_net *net, void *dev_workspace, size_t dev_bytes
  * out_dev: float32, reference layout -- v2 [B,h,w,A*(5+C)], v3 [B,sum(h*w*3),5+C] coarse->fine. */
 int yolo_net_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, void *stream);
 
+/* Optional: time every valid tile configuration of each heavy conv on the device (synchronous, a few
+ * hundred launches) and keep the fastest per layer for later forward/detect calls at this batch. */
+int yolo_net_autotune(yolo_net *net, const float *in_dev, int batch, void *stream);
+
 /* forward + decode + NMS.  boxes_dev: [batch][max_boxes] yolo_box, counts_dev: [batch] int32
  * (number of valid records, descending prob, stable); status_dev: [batch] int32
  * (0 ok, 1 candidate overflow, 2 more survivors than max_boxes: list truncated).

@@ -146,6 +146,62 @@ struct Ptrs {
     unsigned char *view_ptr(const View &v) const { return buf_base(v.buf) + (size_t)(v.base + v.coff) * esz(v); }
 };
 
+// conv launch parameters for one planned kernel at the given batch
+int make_conv_params(yolo_net *net, const Kernel &k, const Ptrs &P, int batch, ConvParams &p) {
+    const int dtype = net->opt.dtype;
+    const int epc = net->epc;
+    memset(&p, 0, sizeof p);
+    const View &in = k.in;
+    const long long in_bytes = (long long)batch * in.img_stride * net->esize;
+    if (in_bytes > 0x7ffffff0LL)
+        return fail(YOLO_ERR_ARG, "conv input tensor exceeds 2 GiB (32-bit buffer addressing): lower the batch");
+    p.in = P.buf_base(in.buf);
+    p.in_bytes = (uint32_t)in_bytes;
+    p.wgt = net->dev_weights + k.w_off;
+    p.wgt_bytes = (uint32_t)k.w_bytes;
+    p.bias = reinterpret_cast<const float *>(net->dev_weights + k.b_off);
+    p.H = in.H; p.W = in.W; p.in_ld = in.ld; p.in_coff = in.coff; p.in_img_stride = in.img_stride;
+    const yolo_layer_desc &d = net->layers[k.src_layer].d;
+    const int Ho = net->layers[k.src_layer].H, Wo = net->layers[k.src_layer].W;
+    p.Ho = Ho; p.Wo = Wo; p.HoWo = Ho * Wo;
+    const long long M = (long long)batch * Ho * Wo;
+    if (M > 0x7fffffffLL) return fail(YOLO_ERR_ARG, "too many output pixels for one launch");
+    p.M = (int)M;
+    p.Cout = k.cout;
+    p.out = P.view_ptr(k.out);
+    p.out_ld = k.out.ld;
+    p.out_img_stride = k.out.img_stride;
+    p.out_f32 = k.out.f32 || dtype == YOLO_DTYPE_F32;
+    p.ksize = d.ksize; p.stride = d.stride; p.pad = (d.ksize - 1) / 2; p.taps = d.ksize * d.ksize;
+    p.ktiles = k.ktiles;
+    p.tiles_per_tap = k.perchunk ? 1 : k.cpt / 8;
+    p.cpt_shift = k.cpt == 1 ? 0 : k.cpt == 2 ? 1 : 2;
+    p.wrow_bytes = (uint32_t)k.ktiles * 128;
+    p.leaky = k.leaky; p.outmode = k.outmode; p.has_res = k.has_res;
+    const int ch = k.cfg == CFG_N32 ? 8 : 16;
+    const int oepc = p.out_f32 ? 4 : epc;
+    p.vec_out = (k.cout % ch == 0) && (k.out.ld % oepc == 0) && ((k.out.base + k.out.coff) % oepc == 0) &&
+                (k.out.img_stride % oepc == 0) && ((uintptr_t)P.buf_base(k.out.buf) % 16 == 0);
+    if (k.has_res) {
+        p.res = P.view_ptr(k.in2);
+        p.res_ld = k.in2.ld;
+        p.res_img_stride = k.in2.img_stride;
+        p.vec_res = (k.cout % ch == 0) && (k.in2.ld % epc == 0) && (k.in2.coff % epc == 0) && (k.in2.img_stride % epc == 0);
+    }
+    return YOLO_OK;
+}
+
+bool dma_eligible(const yolo_net *net, const Kernel &k) {
+    return net->opt.dtype == YOLO_DTYPE_F16 && !k.perchunk && k.cfg == CFG_N128;
+}
+
+// tile < 0: heuristic (choose_dma_cfg); 0: 4-wave kernel of conv.hip; > 0: conv_dma.hip tile id
+hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParams &p, int tile, hipStream_t s) {
+    if (!dma_eligible(net, k)) tile = 0;
+    else if (tile < 0) tile = choose_dma_cfg(p.M, k.cout);
+    return tile ? launch_conv_dma(p, tile, s) : launch_conv(p, net->opt.dtype, k.cfg, k.perchunk != 0, s);
+}
+
 int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, hipStream_t s, hipEvent_t *ev = nullptr) {
     Ptrs P{net, in_dev, out_dev};
     const int dtype = net->opt.dtype;
@@ -167,47 +223,9 @@ int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, h
         }
         case K_CONV: {
             ConvParams p;
-            memset(&p, 0, sizeof p);
-            const View &in = k.in;
-            const long long in_bytes = (long long)batch * in.img_stride * net->esize;
-            if (in_bytes > 0x7ffffff0LL)
-                return fail(YOLO_ERR_ARG, "conv input tensor exceeds 2 GiB (32-bit buffer addressing): lower the batch");
-            p.in = P.buf_base(in.buf);
-            p.in_bytes = (uint32_t)in_bytes;
-            p.wgt = net->dev_weights + k.w_off;
-            p.wgt_bytes = (uint32_t)k.w_bytes;
-            p.bias = reinterpret_cast<const float *>(net->dev_weights + k.b_off);
-            p.H = in.H; p.W = in.W; p.in_ld = in.ld; p.in_coff = in.coff; p.in_img_stride = in.img_stride;
-            const yolo_layer_desc &d = net->layers[k.src_layer].d;
-            const int Ho = net->layers[k.src_layer].H, Wo = net->layers[k.src_layer].W;
-            p.Ho = Ho; p.Wo = Wo; p.HoWo = Ho * Wo;
-            const long long M = (long long)batch * Ho * Wo;
-            if (M > 0x7fffffffLL) return fail(YOLO_ERR_ARG, "too many output pixels for one launch");
-            p.M = (int)M;
-            p.Cout = k.cout;
-            p.out = P.view_ptr(k.out);
-            p.out_ld = k.out.ld;
-            p.out_img_stride = k.out.img_stride;
-            p.out_f32 = k.out.f32 || dtype == YOLO_DTYPE_F32;
-            p.ksize = d.ksize; p.stride = d.stride; p.pad = (d.ksize - 1) / 2; p.taps = d.ksize * d.ksize;
-            p.ktiles = k.ktiles;
-            p.tiles_per_tap = k.perchunk ? 1 : k.cpt / 8;
-            p.cpt_shift = k.cpt == 1 ? 0 : k.cpt == 2 ? 1 : 2;
-            p.wrow_bytes = (uint32_t)k.ktiles * 128;
-            p.leaky = k.leaky; p.outmode = k.outmode; p.has_res = k.has_res;
-            const int ch = k.cfg == CFG_N32 ? 8 : 16;
-            const int oepc = p.out_f32 ? 4 : epc;
-            p.vec_out = (k.cout % ch == 0) && (k.out.ld % oepc == 0) && ((k.out.base + k.out.coff) % oepc == 0) &&
-                        (k.out.img_stride % oepc == 0) && ((uintptr_t)P.buf_base(k.out.buf) % 16 == 0);
-            if (k.has_res) {
-                p.res = P.view_ptr(k.in2);
-                p.res_ld = k.in2.ld;
-                p.res_img_stride = k.in2.img_stride;
-                p.vec_res = (k.cout % ch == 0) && (k.in2.ld % epc == 0) && (k.in2.coff % epc == 0) && (k.in2.img_stride % epc == 0);
-            }
-            int tile = 0;
-            if (dtype == YOLO_DTYPE_F16 && !k.perchunk && k.cfg == CFG_N128) tile = choose_dma_cfg(p.M, k.cout);
-            e = tile ? launch_conv_dma(p, tile, s) : launch_conv(p, dtype, k.cfg, k.perchunk != 0, s);
+            int rc = make_conv_params(net, k, P, batch, p);
+            if (rc) return rc;
+            e = launch_conv_any(net, k, p, k.tile, s);
             break;
         }
         case K_FIRST: {
@@ -352,7 +370,7 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         out->weight_bytes = (double)k.cout * k.ksize * k.ksize * k.cin * net->esize + 4.0 * k.cout;
         int tile = 0;       // which kernel runs at max_batch (bench.py runs at max_batch)
         if (net->opt.dtype == YOLO_DTYPE_F16 && !k.perchunk && k.cfg == CFG_N128)
-            tile = choose_dma_cfg(net->opt.max_batch * li.H * li.W, k.cout);
+            tile = k.tile >= 0 ? k.tile : choose_dma_cfg(net->opt.max_batch * li.H * li.W, k.cout);
         if (tile) {
             out->variant = 8 + tile;
             snprintf(out->name, sizeof out->name, "conv_igemm_dma<f16,%s>", dma_cfg_name(tile));
@@ -372,6 +390,46 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         snprintf(out->name, sizeof out->name, "%s<%s>", k.kind == K_PREP ? "prep" : k.kind == K_POOL ? "pool" : "eltwise", t);
     }
     return YOLO_OK;
+}
+
+int yolo_net_autotune(yolo_net *net, const float *in_dev, int batch, void *stream) {
+    int rc = check_ready(net, in_dev, batch, "yolo_net_autotune");
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float *logits = reinterpret_cast<float *>(net->dev_ws + net->logits_off);
+    rc = run_forward(net, in_dev, batch, logits, s);      // real activations in every buffer
+    if (rc) return rc;
+    Ptrs P{net, in_dev, logits};
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (Kernel &k : net->kernels) {
+        if (k.kind != K_CONV || !dma_eligible(net, k)) continue;
+        ConvParams p;
+        rc = make_conv_params(net, k, P, batch, p);
+        if (rc) break;
+        const int cout_pad = (k.cout + 127) / 128 * 128;
+        float best = 1e30f;
+        int best_tile = -1;
+        for (int tile = 0; tile < dma_num_cfgs(); ++tile) {
+            if (tile && dma_cfg_na(tile) > cout_pad) continue;
+            float ms = 1e30f;
+            bool ok = true;
+            for (int rep = 0; rep < 4 && ok; ++rep) {       // first launch warms caches; keep the best of the rest
+                ok = hipEventRecord(e0, s) == hipSuccess && launch_conv_any(net, k, p, tile, s) == hipSuccess &&
+                     hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+                float t = 0.f;
+                if (ok && rep > 0 && hipEventElapsedTime(&t, e0, e1) == hipSuccess && t < ms) ms = t;
+            }
+            if (!ok) { rc = fail(YOLO_ERR_HIP, "yolo_net_autotune: launch failed"); break; }
+            if (ms < best) { best = ms; best_tile = tile; }
+        }
+        if (rc) break;
+        k.tile = best_tile;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
 }
 
 int yolo_net_detect(yolo_net *net, const float *in_dev, int batch, double threshold, double iou_threshold, int nms_mode,

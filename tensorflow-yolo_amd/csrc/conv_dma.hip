@@ -1,14 +1,17 @@
-// Second-generation implicit-GEMM conv for the heavy fp16 layers: same GEMM view, LDS image and
-// epilogue as conv.hip, but
+// Second-generation implicit-GEMM conv for the heavy fp16 layers: same GEMM view and epilogue as
+// conv.hip, but
 //   * 8 waves (512 threads), one workgroup per CU, block tiles 256x256 / 256x128 / 128x256
-//     (couts x pixels) -> 32..48 B/clk/CU of L2->LDS traffic instead of 64 for the 128x128 tile;
+//     (couts x pixels) -> fewer L2->LDS bytes per FLOP than the 128x128 tile;
 //   * operands go global -> LDS directly with `buffer_load_dwordx4 ... lds` (LDS-DMA): no staging
 //     VGPRs and no ds_write pass (ds_write_b128 tops out at ~79 B/clk/CU and was the bottleneck of
-//     the register-staged kernel).  One wave instruction fills 8 LDS rows x 128 B (lane-linear), the
+//     the register-staged kernel).  One wave instruction fills 1 KiB of LDS rows (lane-linear), the
 //     XOR swizzle is applied to the per-lane SOURCE chunk, zero padding / M tail come from the
 //     buffer range check (verified on gfx950: out-of-range lanes write zeros to LDS);
 //   * an S-stage LDS ring with counted `s_waitcnt vmcnt(N)` and raw `s_barrier`, so the DMA of the
 //     next tile(s) stays in flight across the barrier while the MFMAs of the current tile run.
+//     PMC showed the loop is bound by DMA round-trip latency (~5k cycles under load): throughput =
+//     bytes in flight / latency, so the K depth of a stage (BKC chunks: 64 or 32 halfs) and S are
+//     chosen to keep as much of the 160 KiB LDS in flight as possible (256x256: 4 stages of K=32).
 // Per K tile: wait(tile kt landed) -> barrier -> issue DMA of tile kt+S-1 into the stage read at
 // kt-1 -> ds_read fragments + MFMAs of tile kt.
 #include "conv_common.h"
@@ -33,19 +36,38 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char
 #endif
 }
 
-// WM x WN = 8 waves; a wave owns TM*16 couts x TP*16 pixels; S = LDS ring depth.
-template <int WM, int WN, int TM, int TP, int S>
-__global__ void __launch_bounds__(512) conv_igemm_dma_kernel(const ConvParams p) {
+// LDS image: rows of BKC 16-byte chunks (128 B or 64 B), logical chunk c of row r stored at physical
+// chunk c ^ swz(r).  Chosen so that the ds_read_b128 fragment reads (16 rows x one chunk per 16-lane
+// group, hardware lane groups {0-3,12-15,20-27} ...) hit 16 distinct 16-byte slots of the 256-byte
+// bank window:   BKC = 8: swz = (r >> 1) & 7;   BKC = 4: swz = {0,2,3,1}[(r >> 2) & 3].
+template <int BKC>
+__device__ __forceinline__ int lds_swz(int r) {
+    if (BKC == 8) return (r >> 1) & 7;
+    return (0x78 >> (2 * ((r >> 2) & 3))) & 3;
+}
+
+// WM x WN = 8 waves; a wave owns TM*16 couts x TP*16 pixels; S = LDS ring depth; BKC = K chunks per stage;
+// OCC = waves per SIMD the register budget must allow (2: one workgroup per CU, 4: two per CU, so that
+// one workgroup's epilogue -- ~190 MB of residual reads + output writes per 76x76 layer -- overlaps the
+// other's MFMA loop; with one lock-stepped workgroup per CU that traffic was 44 % of the layer time).
+template <int WM, int WN, int TM, int TP, int S, int BKC, int OCC>
+__global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvParams p) {
     typedef _Float16 T;
     static_assert(WM * WN == 8, "eight waves per workgroup");
-    static_assert(S == 2 || S == 3, "ring depth 2 or 3");
+    static_assert(S >= 2 && S <= 4, "ring depth 2..4");
+    static_assert(BKC == 8 || BKC == 4, "stage depth 64 or 32 halfs");
+    constexpr int ROWB = BKC * 16;          // bytes per LDS row
+    constexpr int RPI = 1024 / ROWB;        // rows one DMA wave-instruction fills (8 or 16)
     constexpr int NA = WM * TM * 16;        // couts per block
     constexpr int NB = WN * TP * 16;        // pixels per block
-    constexpr int JA = NA / 64;             // DMA wave-instructions per wave per tile (weights)
-    constexpr int JB = NB / 64;             //                                        (pixels)
+    constexpr int JA = NA / (8 * RPI);      // DMA wave-instructions per wave per stage (weights)
+    constexpr int JB = NB / (8 * RPI);      //                                          (pixels)
     constexpr int NL = JA + JB;
+    constexpr int KS = BKC / 4;             // 32-deep MFMA k-steps per stage
+    constexpr int SUB = 8 / BKC;            // stages per 64-half K tile of the host-side plan
     constexpr int CH = 4 * TM;
-    constexpr int TILE_BYTES = (NA + NB) * 128;
+    constexpr int TILE_BYTES = (NA + NB) * ROWB;
+    static_assert(JA >= 1 && JB >= 1, "tile too small for the DMA mapping");
     __shared__ __attribute__((aligned(16))) unsigned char smem[S * TILE_BYTES];
 
     const int tid = threadIdx.x;
@@ -59,20 +81,29 @@ __global__ void __launch_bounds__(512) conv_igemm_dma_kernel(const ConvParams p)
     const int n0 = nt * NA;
     const int m0 = mt * NB;
 
+    // Two workgroups share a CU (OCC 4).  Dispatched together they would run in lockstep -- both in
+    // the MFMA loop, then both in the memory-bound epilogue.  The second resident workgroup of each
+    // CU (observed placement: blocks 256..511 of the first wave; speed only, never correctness)
+    // sleeps for about half a workgroup period once, so from then on one computes while the other
+    // loads residuals / stores outputs.
+    if (OCC == 4 && p.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wgt), 0, p.wgt_bytes, 0x00020000);
 
     // ---- DMA geometry ---------------------------------------------------------------------------
-    // wave instruction j of wave w fills row group g = 8 j + w (8 rows x 128 B = 1 KiB, lane-linear):
-    // lane -> row 8 g + (lane >> 3), PHYSICAL chunk lane & 7, which must hold LOGICAL chunk
-    // phys ^ ((row >> 1) & 7) = phys ^ ((4 (w & 1) + (lane >> 4)) & 7)   (same for every j).
-    const int lrow = lane >> 3;
-    const uint32_t csw = (uint32_t)(((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) << 4);
+    // wave instruction j of wave w fills row group g = 8 j + w (RPI rows = 1 KiB, lane-linear):
+    // lane -> row RPI g + lane / BKC, PHYSICAL chunk lane % BKC, which must hold LOGICAL chunk
+    // phys ^ swz(row).  swz(row) only depends on (w & 1, lane) [BKC 8] or lane [BKC 4]: same for all j.
+    const int lrow = lane / BKC;
+    const uint32_t csw = (uint32_t)(((lane % BKC) ^ lds_swz<BKC>(RPI * (wave & 1) + lrow)) << 4);
 
     uint32_t a_off[JA];
 #pragma unroll
     for (int j = 0; j < JA; ++j) {
-        const int r = (j * 8 + wave) * 8 + lrow;                // LDS row of the weight tile
+        const int r = (j * 8 + wave) * RPI + lrow;              // LDS row of the weight tile
         const int ws = r / (TM * 16), R = r % (TM * 16);
         const int tm = R >> 4, g4 = (R >> 2) & 3, jj = R & 3;
         const int ch = ws * (TM * 16) + g4 * CH + 4 * tm + jj;  // the cout that LDS row holds
@@ -81,7 +112,7 @@ __global__ void __launch_bounds__(512) conv_igemm_dma_kernel(const ConvParams p)
     uint32_t b_base[JB], b_mask[JB];
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
-        const int m = m0 + (j * 8 + wave) * 8 + lrow;
+        const int m = m0 + (j * 8 + wave) * RPI + lrow;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
         const int n = mm / p.HoWo;
@@ -101,21 +132,22 @@ __global__ void __launch_bounds__(512) conv_igemm_dma_kernel(const ConvParams p)
         b_mask[j] = mask;
     }
 
+    const int tpt = p.tiles_per_tap * SUB;  // stages per tap
     auto issue_tile = [&](int kt, int stage) {
         unsigned char *base = smem + stage * TILE_BYTES + wave * 1024;
-        const uint32_t ka = (uint32_t)kt * 128;
+        const uint32_t ka = (uint32_t)kt * ROWB;
 #pragma unroll
         for (int j = 0; j < JA; ++j)
             dma16(rs_w, base + j * 8192, a_off[j] + ka);
-        const int tap = kt / p.tiles_per_tap;
-        const uint32_t koff = (uint32_t)(kt - tap * p.tiles_per_tap) * 128;
+        const int tap = kt / tpt;
+        const uint32_t koff = (uint32_t)(kt - tap * tpt) * ROWB;
         const int kh = p.ksize == 3 ? (tap * 11) >> 5 : 0;
         const int kw = tap - kh * p.ksize;
         const uint32_t toff = (uint32_t)((kh * p.W + kw) * p.in_ld * 2) + koff;
 #pragma unroll
         for (int j = 0; j < JB; ++j) {
             const bool ok = (b_mask[j] >> tap) & 1u;
-            dma16(rs_in, base + NA * 128 + j * 8192, ok ? b_base[j] + toff : YOLO_INVALID_OFF);
+            dma16(rs_in, base + NA * ROWB + j * 8192, ok ? b_base[j] + toff : YOLO_INVALID_OFF);
         }
     };
 
@@ -126,17 +158,18 @@ __global__ void __launch_bounds__(512) conv_igemm_dma_kernel(const ConvParams p)
         for (int b = 0; b < TP; ++b) acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
+    const int fswz = lds_swz<BKC>(fr);      // fragment rows are 16-aligned + fr
     auto compute = [&](int stage) {
-        const unsigned char *A = smem + stage * TILE_BYTES + (wm * TM * 16 + fr) * 128;
-        const unsigned char *B = smem + stage * TILE_BYTES + NA * 128 + (wn * TP * 16 + fr) * 128;
+        const unsigned char *A = smem + stage * TILE_BYTES + (wm * TM * 16 + fr) * ROWB;
+        const unsigned char *B = smem + stage * TILE_BYTES + NA * ROWB + (wn * TP * 16 + fr) * ROWB;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int so = (((ks * 4 + fq) ^ (fr >> 1)) & 7) << 4;
+        for (int ks = 0; ks < KS; ++ks) {
+            const int so = (((ks * 4 + fq) ^ fswz) & (BKC - 1)) << 4;
             uint4v fa[TM], fb[TP];
 #pragma unroll
-            for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const uint4v *>(A + a * 16 * 128 + so);
+            for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const uint4v *>(A + a * 16 * ROWB + so);
 #pragma unroll
-            for (int b = 0; b < TP; ++b) fb[b] = *reinterpret_cast<const uint4v *>(B + b * 16 * 128 + so);
+            for (int b = 0; b < TP; ++b) fb[b] = *reinterpret_cast<const uint4v *>(B + b * 16 * ROWB + so);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -145,36 +178,44 @@ __global__ void __launch_bounds__(512) conv_igemm_dma_kernel(const ConvParams p)
     };
 
     // ---- main loop: S-stage ring, counted vmcnt, raw barrier ------------------------------------
-    const int KT = p.ktiles;
+    const int KT = p.ktiles * SUB;
 #pragma unroll
     for (int s = 0; s < S - 1; ++s)
         if (s < KT) issue_tile(s, s);
     int stage = 0;                  // stage holding tile kt
     int fill = S - 1;               // stage that tile kt+S-1 goes to (== the stage read at kt-1)
     for (int kt = 0; kt < KT; ++kt) {
-        // tiles issued after tile kt and still allowed in flight: min(S-2, KT-1-kt)
-        if (S == 3 && kt + 1 < KT) wait_vmcnt<NL>();
+        // tiles issued after tile kt that may stay in flight: min(S-2, KT-1-kt)
+        const int after = KT - 1 - kt;
+        if (S >= 4 && after >= 2) wait_vmcnt<2 * NL>();
+        else if (S >= 3 && after >= 1) wait_vmcnt<NL>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();       // tile kt visible to every wave; stage `fill` no longer read
-        if (kt + S - 1 < KT) issue_tile(kt + S - 1, fill);
-        compute(stage);
+        if (kt + S - 1 < KT && !(p.dbg & 1)) issue_tile(kt + S - 1, fill);
+        if (!(p.dbg & 2)) compute(stage);
         stage = stage + 1 == S ? 0 : stage + 1;
         fill = fill + 1 == S ? 0 : fill + 1;
     }
 
+    if (p.dbg & 4) return;             // experiment: no epilogue
     conv_epilogue<T, TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH, m0 + wn * (TP * 16), fr);
 }
 
 struct DmaCfg {
     int na, nb, slots_per_cu;
     float rate;     // relative per-CU throughput while busy (measured ordering, refined by profiling)
+    const char *name;
 };
 static const DmaCfg kCfgs[] = {
-    {128, 128, 2, 0.55f},   // 0: conv.hip 4-wave register-staged kernel (two workgroups per CU)
-    {256, 256, 1, 1.00f},   // 1
-    {256, 128, 1, 0.85f},   // 2: 256 couts x 128 pixels
-    {128, 256, 1, 0.85f},   // 3: 128 couts x 256 pixels
+    {128, 128, 2, 0.55f, ""},                   // 0: conv.hip 4-wave register-staged kernel (two workgroups per CU)
+    {256, 256, 1, 0.80f, "256x256,K64,S2"},     // 1
+    {256, 128, 1, 0.85f, "256x128,K64,S3"},     // 2: 256 couts x 128 pixels
+    {128, 256, 1, 0.85f, "128x256,K64,S3"},     // 3: 128 couts x 256 pixels
+    {256, 256, 1, 1.00f, "256x256,K32,S4"},     // 4: 96 KiB in flight instead of 64
+    {256, 128, 2, 1.30f, "256x128,K32,S3,x2"},  // 5: 72 KiB LDS, <=128 VGPRs: two workgroups per CU
+    {128, 256, 2, 1.30f, "128x256,K32,S3,x2"},  // 6
 };
+static const int kNumCfgs = 7;
 
 // Pick the block tile that minimises rounds x tile time on 256 CUs (tail quantisation matters:
 // e.g. 38x38x512 at batch 32 is 362 tiles of 256x256 = 2 rounds at 71 % but 722 of 256x128 = 3 at 94 %).
@@ -184,7 +225,7 @@ int choose_dma_cfg(int M, int cout) {
     const int cout_pad = (cout + 127) / 128 * 128;
     int best = 0;
     double best_t = 1e300;
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < kNumCfgs; ++c) {
         const DmaCfg &k = kCfgs[c];
         if (k.na > cout_pad) continue;
         const long long blocks = ((long long)M + k.nb - 1) / k.nb * ((cout + k.na - 1) / k.na);
@@ -195,27 +236,32 @@ int choose_dma_cfg(int M, int cout) {
     return best;
 }
 
-const char *dma_cfg_name(int cfg) {
-    switch (cfg) {
-    case 1: return "256x256,S2";
-    case 2: return "256x128,S3";
-    case 3: return "128x256,S3";
-    default: return "";
-    }
-}
+int dma_num_cfgs() { return kNumCfgs; }
+int dma_cfg_na(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg].na : 128; }
+const char *dma_cfg_name(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg].name : ""; }
 
 hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
+    if (cfg <= 0 || cfg >= kNumCfgs) return hipErrorInvalidValue;
     ConvParams p = p0;
     const DmaCfg &k = kCfgs[cfg];
+    { const char *d = getenv("YOLO_CONV_DBG"); p.dbg = d ? atoi(d) : 0; }
+    {   // stagger = f x (estimated MFMA-bound K-loop time of one workgroup sharing the CU) in 8128-cycle sleeps
+        const char *d = getenv("YOLO_CONV_STAGGER");
+        const double f = d ? atof(d) : 0.0;
+        p.stagger = k.slots_per_cu == 2 ? (int)(f * p.ktiles * 2 * 1365.0 / 8128.0 + 0.5) : 0;
+    }
     p.n_tiles_n = (p.Cout + k.na - 1) / k.na;
     const long long blocks = ((long long)p.M + k.nb - 1) / k.nb * p.n_tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     p.n_blocks = (int)blocks;
     const dim3 grid((unsigned)blocks), block(512);
     switch (cfg) {
-    case 1: hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 8, 4, 2>), grid, block, 0, s, p); break;
-    case 2: hipLaunchKernelGGL((conv_igemm_dma_kernel<4, 2, 4, 4, 3>), grid, block, 0, s, p); break;
-    case 3: hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 4, 4, 3>), grid, block, 0, s, p); break;
+    case 1: hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 8, 4, 2, 8, 2>), grid, block, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((conv_igemm_dma_kernel<4, 2, 4, 4, 3, 8, 2>), grid, block, 0, s, p); break;
+    case 3: hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 4, 4, 3, 8, 2>), grid, block, 0, s, p); break;
+    case 4: hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 8, 4, 4, 4, 2>), grid, block, 0, s, p); break;
+    case 5: hipLaunchKernelGGL((conv_igemm_dma_kernel<4, 2, 4, 4, 3, 4, 4>), grid, block, 0, s, p); break;
+    case 6: hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 4, 4, 3, 4, 4>), grid, block, 0, s, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

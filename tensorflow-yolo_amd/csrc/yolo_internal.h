@@ -62,6 +62,8 @@ struct ConvParams {
     uint32_t wrow_bytes;
     int leaky, has_res, outmode, out_f32, vec_out, vec_res;
     int n_tiles_n, n_blocks;
+    int stagger;               // conv_dma x2 tiles: initial sleep (x8128 cycles) of the second resident workgroup
+    int dbg;                   // experiment flags (YOLO_CONV_DBG): 1 skip steady-state DMA, 2 skip MFMA phase
 };
 
 struct PrepParams {            // float32 NHWC [B,H,W,C] -> T NHWC [B,H,W,Cpad], zero fill
@@ -141,6 +143,8 @@ hipError_t launch_conv(const ConvParams &p, int dtype, int cfg, bool perchunk, h
 int choose_dma_cfg(int M, int cout);
 hipError_t launch_conv_dma(const ConvParams &p, int cfg, hipStream_t s);
 const char *dma_cfg_name(int cfg);
+int dma_num_cfgs();
+int dma_cfg_na(int cfg);
 hipError_t launch_prep(const PrepParams &p, int dtype, hipStream_t s);
 hipError_t launch_first(const FirstParams &p, int dtype, hipStream_t s);
 hipError_t launch_pool(const PoolParams &p, int dtype, hipStream_t s);
@@ -158,6 +162,7 @@ struct Kernel {
     // conv
     int ksize = 0, stride = 0, cout = 0, cin = 0, cin_s = 0, leaky = 0, outmode = 0, has_res = 0;
     int cfg = 0, perchunk = 0, cpt = 0, ktiles = 0;
+    int tile = -1;             // conv_dma tile id chosen by yolo_net_autotune (-1: heuristic)
     size_t w_off = 0, b_off = 0, w_bytes = 0;   // inside the device weight blob
     size_t w_src = 0;                           // first float of this conv in the Darknet stream
     int batch_norm = 0;

@@ -195,6 +195,12 @@ class HipNetwork(Plan):
                                                 self._counts[1].data_ptr(), self._stream()), "yolo_net_detect")
         return self._boxes[:b], self._counts[0, :b], self._counts[1, :b]
 
+    def autotune(self, x):
+        """Pick the fastest conv tile per layer by timing them on the device (optional, synchronous)."""
+        x = self.to_device(x)
+        with self.torch.cuda.device(self.device):
+            _hip.check(self.lib.yolo_net_autotune(self.handle, x.data_ptr(), x.shape[0], self._stream()), "yolo_net_autotune")
+
     def kernel_infos(self):
         out = []
         for k in range(self.num_kernels):

@@ -60,3 +60,20 @@ def test_known_answer_sizes_from_the_library():
         net, _ = build(kind, size)
         p = engine.Plan(net, dtype="fp16", max_batch=2)
         assert p.weight_count == wc and p.output_count == oc and round(p.flops_per_image / 1e9, 3) == gf
+
+
+def test_autotune_keeps_results():
+    """yolo_net_autotune only swaps tile shapes: logits stay within fp16 summation-order noise and the
+    plan reports the tuned kernels"""
+    from tensorflow_yolo_amd.net import engine
+    net, nc = build("v3", 160)
+    w = synth.darknet_stream(net, seed=5, num_classes=nc)
+    x = synth.synthetic_input(4, 160, 160, 3, seed=6)
+    eng = engine.HipNetwork(net, dtype="fp16", max_batch=4)
+    eng.load_weights(w)
+    before = eng.forward(x).cpu().numpy()
+    eng.autotune(x)
+    after = eng.forward(x).cpu().numpy()
+    assert rel_err(after, before) <= 2e-2
+    names = {ki.name.decode() for ki in eng.kernel_infos()}
+    assert any(n.startswith("conv_igemm") for n in names)
