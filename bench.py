@@ -132,16 +132,12 @@ def main():
     xs = [torch.from_numpy(synth.synthetic_input(batch, size, size, 3, seed=1000 + 17 * rank + i)).to(dev) for i in range(2)]
     if not args.no_autotune:
         eng.autotune(xs[0])     # per-layer conv tile choice, timed on this device (outside the timed region)
-    gathered = None
-    if world > 1:
-        gathered = torch.empty((world * batch, eng.max_boxes, 6), dtype=torch.float32, device=dev)
-        gcounts = torch.empty((world * batch,), dtype=torch.int32, device=dev)
+    from tensorflow_yolo_amd.net import dist as ydist
 
     def step(i):
         boxes, counts, status = eng.detect(xs[i & 1], args.threshold, args.iou_threshold)
         if world > 1:       # the only exchange of the path: fixed-size box records, rank order == image order
-            dist.all_gather_into_tensor(gathered, boxes.contiguous())
-            dist.all_gather_into_tensor(gcounts, counts.contiguous())
+            ydist.gather_records(boxes, counts, status)
         return boxes, counts, status
 
     def fence():

@@ -175,6 +175,7 @@ int make_conv_params(yolo_net *net, const Kernel &k, const Ptrs &P, int batch, C
     p.ksize = d.ksize; p.stride = d.stride; p.pad = (d.ksize - 1) / 2; p.taps = d.ksize * d.ksize;
     p.ktiles = k.ktiles;
     p.tiles_per_tap = k.perchunk ? 1 : k.cpt / 8;
+    p.cin_chunks = k.cpt;
     p.cpt_shift = k.cpt == 1 ? 0 : k.cpt == 2 ? 1 : 2;
     p.wrow_bytes = (uint32_t)k.ktiles * 128;
     p.leaky = k.leaky; p.outmode = k.outmode; p.has_res = k.has_res;
@@ -191,15 +192,21 @@ int make_conv_params(yolo_net *net, const Kernel &k, const Ptrs &P, int batch, C
     return YOLO_OK;
 }
 
+// the LDS-DMA kernels take fp16 convs whose Cin is a multiple of 4 chunks (32 channels)
 bool dma_eligible(const yolo_net *net, const Kernel &k) {
-    return net->opt.dtype == YOLO_DTYPE_F16 && !k.perchunk && k.cfg == CFG_N128;
+    return net->opt.dtype == YOLO_DTYPE_F16 && k.cpt % 4 == 0;
+}
+// tile 0 = the 4-wave kernel of conv.hip with the planner's cfg (always available)
+bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile) {
+    if (tile == 0) return true;
+    return dma_eligible(net, k) && dma_cfg_valid(tile, k.cout, k.cpt, true);
 }
 
 // tile < 0: heuristic (choose_dma_cfg); 0: 4-wave kernel of conv.hip; > 0: conv_dma.hip tile id
 hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParams &p, int tile, hipStream_t s) {
     if (!dma_eligible(net, k)) tile = 0;
-    else if (tile < 0) tile = choose_dma_cfg(p.M, k.cout);
-    return tile ? launch_conv_dma(p, tile, s) : launch_conv(p, net->opt.dtype, k.cfg, k.perchunk != 0, s);
+    else if (tile < 0) tile = choose_dma_cfg(p.M, k.cout, k.cpt, true);
+    return tile > 0 ? launch_conv_dma(p, tile, s) : launch_conv(p, net->opt.dtype, k.cfg, k.perchunk != 0, s);
 }
 
 int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, hipStream_t s, hipEvent_t *ev = nullptr) {
@@ -369,9 +376,9 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         out->bytes = (double)k.in.H * k.in.W * k.cin * net->esize + elems(k.out) * esz(k.out) + (k.has_res ? elems(k.in2) * net->esize : 0.0);
         out->weight_bytes = (double)k.cout * k.ksize * k.ksize * k.cin * net->esize + 4.0 * k.cout;
         int tile = 0;       // which kernel runs at max_batch (bench.py runs at max_batch)
-        if (net->opt.dtype == YOLO_DTYPE_F16 && !k.perchunk && k.cfg == CFG_N128)
-            tile = k.tile >= 0 ? k.tile : choose_dma_cfg(net->opt.max_batch * li.H * li.W, k.cout);
-        if (tile) {
+        if (dma_eligible(net, k))
+            tile = k.tile >= 0 ? k.tile : choose_dma_cfg(net->opt.max_batch * li.H * li.W, k.cout, k.cpt, true);
+        if (tile > 0) {
             out->variant = 8 + tile;
             snprintf(out->name, sizeof out->name, "conv_igemm_dma<f16,%s>", dma_cfg_name(tile));
         } else {
@@ -408,11 +415,10 @@ int yolo_net_autotune(yolo_net *net, const float *in_dev, int batch, void *strea
         ConvParams p;
         rc = make_conv_params(net, k, P, batch, p);
         if (rc) break;
-        const int cout_pad = (k.cout + 127) / 128 * 128;
         float best = 1e30f;
         int best_tile = -1;
         for (int tile = 0; tile < dma_num_cfgs(); ++tile) {
-            if (tile && dma_cfg_na(tile) > cout_pad) continue;
+            if (!conv_tile_valid(net, k, tile)) continue;
             float ms = 1e30f;
             bool ok = true;
             for (int rep = 0; rep < 4 && ok; ++rep) {       // first launch warms caches; keep the best of the rest

@@ -60,20 +60,23 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
     constexpr int RPI = 1024 / ROWB;        // rows one DMA wave-instruction fills (8 or 16)
     constexpr int NA = WM * TM * 16;        // couts per block
     constexpr int NB = WN * TP * 16;        // pixels per block
-    constexpr int JA = NA / (8 * RPI);      // DMA wave-instructions per wave per stage (weights)
-    constexpr int JB = NB / (8 * RPI);      //                                          (pixels)
-    constexpr int NL = JA + JB;
+    constexpr int JA_TOT = NA / RPI;        // weight DMA wave-instructions per stage, dealt round-robin to the waves
+    constexpr int JA = (JA_TOT + 7) / 8;    // per wave (waves >= JA_TOT carry none when the weight tile is small)
+    constexpr int JB = NB / (8 * RPI);      // pixel DMA wave-instructions per wave per stage
+    constexpr bool A_ALL = JA_TOT % 8 == 0; // every wave issues the same number of weight instructions
+    constexpr int NL = JA + JB;             // DMA instructions per stage of a wave that carries weights
     constexpr int KS = BKC / 4;             // 32-deep MFMA k-steps per stage
     constexpr int SUB = 8 / BKC;            // stages per 64-half K tile of the host-side plan
     constexpr int CH = 4 * TM;
     constexpr int TILE_BYTES = (NA + NB) * ROWB;
-    static_assert(JA >= 1 && JB >= 1, "tile too small for the DMA mapping");
+    static_assert(JB >= 1 && (A_ALL || JA_TOT < 8), "unsupported tile for the DMA mapping");
     __shared__ __attribute__((aligned(16))) unsigned char smem[S * TILE_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    const bool has_a = A_ALL || wave < JA_TOT;     // wave-uniform
 
     const int bid = xcd_remap(blockIdx.x, p.n_blocks);
     const int nt = bid % p.n_tiles_n;
@@ -132,13 +135,15 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
         b_mask[j] = mask;
     }
 
-    const int tpt = p.tiles_per_tap * SUB;  // stages per tap
+    const int tpt = p.cin_chunks / BKC;     // stages per tap (Cin is a multiple of BKC chunks)
     auto issue_tile = [&](int kt, int stage) {
         unsigned char *base = smem + stage * TILE_BYTES + wave * 1024;
         const uint32_t ka = (uint32_t)kt * ROWB;
+        if (has_a) {
 #pragma unroll
-        for (int j = 0; j < JA; ++j)
-            dma16(rs_w, base + j * 8192, a_off[j] + ka);
+            for (int j = 0; j < JA; ++j)
+                dma16(rs_w, base + j * 8192, a_off[j] + ka);
+        }
         const int tap = kt / tpt;
         const uint32_t koff = (uint32_t)(kt - tap * tpt) * ROWB;
         const int kh = p.ksize == 3 ? (tap * 11) >> 5 : 0;
@@ -178,7 +183,7 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
     };
 
     // ---- main loop: S-stage ring, counted vmcnt, raw barrier ------------------------------------
-    const int KT = p.ktiles * SUB;
+    const int KT = p.taps * tpt;
 #pragma unroll
     for (int s = 0; s < S - 1; ++s)
         if (s < KT) issue_tile(s, s);
@@ -187,9 +192,15 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
     for (int kt = 0; kt < KT; ++kt) {
         // tiles issued after tile kt that may stay in flight: min(S-2, KT-1-kt)
         const int after = KT - 1 - kt;
-        if (S >= 4 && after >= 2) wait_vmcnt<2 * NL>();
-        else if (S >= 3 && after >= 1) wait_vmcnt<NL>();
-        else wait_vmcnt<0>();
+        if (has_a) {
+            if (S >= 4 && after >= 2) wait_vmcnt<2 * NL>();
+            else if (S >= 3 && after >= 1) wait_vmcnt<NL>();
+            else wait_vmcnt<0>();
+        } else {
+            if (S >= 4 && after >= 2) wait_vmcnt<2 * JB>();
+            else if (S >= 3 && after >= 1) wait_vmcnt<JB>();
+            else wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();       // tile kt visible to every wave; stage `fill` no longer read
         if (kt + S - 1 < KT && !(p.dbg & 1)) issue_tile(kt + S - 1, fill);
         if (!(p.dbg & 2)) compute(stage);
@@ -205,29 +216,39 @@ struct DmaCfg {
     int na, nb, slots_per_cu;
     float rate;     // relative per-CU throughput while busy (measured ordering, refined by profiling)
     const char *name;
+    int bkc;        // K chunks per stage: Cin must be a multiple of it
 };
 static const DmaCfg kCfgs[] = {
-    {128, 128, 2, 0.55f, ""},                   // 0: conv.hip 4-wave register-staged kernel (two workgroups per CU)
-    {256, 256, 1, 0.80f, "256x256,K64,S2"},     // 1
-    {256, 128, 1, 0.85f, "256x128,K64,S3"},     // 2: 256 couts x 128 pixels
-    {128, 256, 1, 0.85f, "128x256,K64,S3"},     // 3: 128 couts x 256 pixels
-    {256, 256, 1, 1.00f, "256x256,K32,S4"},     // 4: 96 KiB in flight instead of 64
-    {256, 128, 2, 1.30f, "256x128,K32,S3,x2"},  // 5: 72 KiB LDS, <=128 VGPRs: two workgroups per CU
-    {128, 256, 2, 1.30f, "128x256,K32,S3,x2"},  // 6
+    {128, 128, 2, 0.55f, "", 8},                   // 0: conv.hip 4-wave register-staged kernel (two workgroups per CU)
+    {256, 256, 1, 0.80f, "256x256,K64,S2", 8},     // 1
+    {256, 128, 1, 0.85f, "256x128,K64,S3", 8},     // 2: 256 couts x 128 pixels
+    {128, 256, 1, 0.85f, "128x256,K64,S3", 8},     // 3: 128 couts x 256 pixels
+    {256, 256, 1, 1.00f, "256x256,K32,S4", 4},     // 4: 96 KiB in flight instead of 64
+    {256, 128, 2, 1.30f, "256x128,K32,S3,x2", 4},  // 5: 72 KiB LDS, <=128 VGPRs: two workgroups per CU
+    {128, 256, 2, 1.30f, "128x256,K32,S3,x2", 4},  // 6
+    {64, 512, 2, 1.00f, "64x512,K32,S2,x2", 4},    // 7: narrow early layers (Cout <= 64), bandwidth-bound
 };
-static const int kNumCfgs = 7;
+static const int kNumCfgs = 8;
 
 // Pick the block tile that minimises rounds x tile time on 256 CUs (tail quantisation matters:
 // e.g. 38x38x512 at batch 32 is 362 tiles of 256x256 = 2 rounds at 71 % but 722 of 256x128 = 3 at 94 %).
-int choose_dma_cfg(int M, int cout) {
+bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok) {
+    if (cfg == 0) return v1_ok;
+    if (cfg < 0 || cfg >= kNumCfgs) return false;
+    const DmaCfg &k = kCfgs[cfg];
+    if (cin_chunks % k.bkc) return false;
+    if (k.na == 64) return cout <= 64;
+    return k.na <= (cout + 127) / 128 * 128 && cout > 64;
+}
+
+int choose_dma_cfg(int M, int cout, int cin_chunks, bool v1_ok) {
     const char *force = getenv("YOLO_CONV_TILE");
-    if (force && *force) return atoi(force);
-    const int cout_pad = (cout + 127) / 128 * 128;
-    int best = 0;
+    if (force && *force && dma_cfg_valid(atoi(force), cout, cin_chunks, v1_ok)) return atoi(force);
+    int best = v1_ok ? 0 : -1;
     double best_t = 1e300;
     for (int c = 0; c < kNumCfgs; ++c) {
         const DmaCfg &k = kCfgs[c];
-        if (k.na > cout_pad) continue;
+        if (!dma_cfg_valid(c, cout, cin_chunks, v1_ok)) continue;
         const long long blocks = ((long long)M + k.nb - 1) / k.nb * ((cout + k.na - 1) / k.na);
         const long long rounds = (blocks + 256LL * k.slots_per_cu - 1) / (256LL * k.slots_per_cu);
         const double t = (double)rounds * k.na * k.nb * k.slots_per_cu / k.rate;
@@ -238,6 +259,7 @@ int choose_dma_cfg(int M, int cout) {
 
 int dma_num_cfgs() { return kNumCfgs; }
 int dma_cfg_na(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg].na : 128; }
+int dma_cfg_bkc(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg].bkc : 8; }
 const char *dma_cfg_name(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg].name : ""; }
 
 hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
@@ -262,6 +284,7 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
     case 4: hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 8, 4, 4, 4, 2>), grid, block, 0, s, p); break;
     case 5: hipLaunchKernelGGL((conv_igemm_dma_kernel<4, 2, 4, 4, 3, 4, 4>), grid, block, 0, s, p); break;
     case 6: hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 4, 4, 3, 4, 4>), grid, block, 0, s, p); break;
+    case 7: hipLaunchKernelGGL((conv_igemm_dma_kernel<1, 8, 4, 4, 2, 4, 4>), grid, block, 0, s, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -59,6 +59,7 @@ struct ConvParams {
     long long res_img_stride;
     int ksize, stride, pad, taps;
     int ktiles, tiles_per_tap, cpt_shift;
+    int cin_chunks;            // 16-byte chunks per tap (storage channels / EPC)
     uint32_t wrow_bytes;
     int leaky, has_res, outmode, out_f32, vec_out, vec_res;
     int n_tiles_n, n_blocks;
@@ -140,7 +141,9 @@ struct NmsParams {
 hipError_t launch_conv(const ConvParams &p, int dtype, int cfg, bool perchunk, hipStream_t s);
 // conv_dma.hip: 8-wave LDS-DMA kernel for the heavy fp16 layers.  choose_dma_cfg returns 0 when the
 // 4-wave kernel of conv.hip should run, else the tile id for launch_conv_dma.
-int choose_dma_cfg(int M, int cout);
+int choose_dma_cfg(int M, int cout, int cin_chunks, bool v1_ok);   // -1: no DMA tile and no 4-wave kernel fits
+bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok);
+int dma_cfg_bkc(int cfg);
 hipError_t launch_conv_dma(const ConvParams &p, int cfg, hipStream_t s);
 const char *dma_cfg_name(int cfg);
 int dma_num_cfgs();

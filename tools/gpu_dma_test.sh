@@ -3,7 +3,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
-for tile in "" 5 6; do
+for tile in "" 7 5 4; do
   export YOLO_CONV_TILE="$tile"
   [ -z "$tile" ] && unset YOLO_CONV_TILE
   timeout -k 10 400 python -m pytest tests/test_gpu_ops.py tests/test_gpu_nets.py -m gpu -q -p no:cacheprovider -k "fp16" > gpurun_out/pytest_tile_${tile:-auto}.log 2>&1
