@@ -6,11 +6,11 @@ on N MI355X GPUs of one node, one process per GPU.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = one pass of the hot path over one synthetic batch resident in HBM: float32 NHWC input ->
-libyolo_hip detect (prep + 75 fused convs + decode + NMS) [-> RCCL all-gather of the fixed-size box
+libyolo_hip detect (75 fused convs + decode + NMS) [-> RCCL all-gather of the fixed-size box
 records when N > 1].  Images shard over ranks (weak scaling: every rank runs the full per-GPU batch).
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     dominant kernel family (the N128 implicit-GEMM conv): algorithmic FLOPs of its launches
+  "roofline":     dominant kernel family (the implicit-GEMM conv tile with most device time): algorithmic FLOPs of its launches
                   / their device time measured with hipEvents on the launch stream (instrumented steps
                   run right after the timed region; the events add bubbles so they never time `value`)
   "cpu_baseline": the CPU oracle (torch-CPU restatement of the reference's TF path + NumPy decode/NMS,
@@ -193,7 +193,10 @@ def main():
         tj = os.path.join(ROOT, "profiles", "traffic.json")      # HBM bytes per launch from rocprofv3 --pmc passes, if recorded
         if os.path.exists(tj):
             try:
-                roof["traffic"] = json.load(open(tj)).get(args.workload, {}).get(dom)
+                rec = json.load(open(tj)).get(args.workload, {}).get(dom)
+                if rec:     # recorded under rocprofv3 --pmc for this kernel family (may predate a retune)
+                    roof["traffic"] = rec["hbm_bytes_per_launch"]
+                    roof["traffic_detail"] = dict(rec, source="profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)")
             except Exception:
                 pass
         if args.dump_kernels:

@@ -193,3 +193,27 @@ def test_errors_are_reported():
         eng.forward(synth.synthetic_input(1, 8, 8, 3))
     with pytest.raises(_hip.YoloHipError, match="weight stream holds"):
         eng.load_weights(np.zeros(5, np.float32))
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
+def test_every_dma_tile_config(tile, monkeypatch):
+    """each LDS-DMA tile shape of conv_dma.hip, forced through YOLO_CONV_TILE (read at every launch; a tile
+    that is not valid for a layer falls back to the heuristic), on a graph with 3x3/1, 3x3/2, 1x1, residual,
+    Cin=32 (one tap per K=32 stage), Cout=64 (weight tile smaller than the wave count) and M tails"""
+    monkeypatch.setenv("YOLO_CONV_TILE", str(tile))
+    g = new_graph(20, 24, 3)
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))                  # 1  first-layer kernel
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 3, 2))                  # 2  Cin 32, Cout 64 (tile 7)
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 1, 1))                  # 3
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 3, 1))                  # 4
+    g.append(PL.shortcut(g[-1].out, g[-3].out))                      # 5  fused residual
+    g.append(PL.conv2d_bn_act(g[-1].out, 128, 3, 2))                 # 6  Cin 64
+    g.append(PL.conv2d_bn_act(g[-1].out, 256, 3, 1))                 # 7  Cin 128 -> 256 (tiles 1-6)
+    g.append(PL.conv2d_bn_act(g[-1].out, 128, 1, 1))                 # 8
+    g.append(PL.conv2d_bn_act(g[-1].out, 256, 3, 1))                 # 9
+    g.append(PL.shortcut(g[-1].out, g[-3].out))                      # 10
+    g.append(PL.conv2d_bn_act(g[-1].out, 255, 1, 1, use_batch_normalization=False, activation_fn="linear"))   # 11 head
+    x = synth.synthetic_input(3, 20, 24, 3, seed=11)
+    eng = check_graph(g, x, "fp16", seed=3, read=(2, 5, 7, 10))
+    names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
+    assert "conv_igemm_dma" in names

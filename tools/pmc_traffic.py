@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc passes (tools/gpu_pmc.sh) -> profiles/traffic.json: HBM bytes per launch of every kernel
+family bench.py names (FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM': on gfx950 it reports half the bytes of a
+wide coalesced stream; WRITE_SIZE as is; both in KiB)."""
+import csv, glob, json, os, re, sys
+from collections import defaultdict
+
+root = sys.argv[1]
+workload = sys.argv[2] if len(sys.argv) > 2 else "v3-608-b32-fp16"
+out_path = sys.argv[3] if len(sys.argv) > 3 else "profiles/traffic.json"
+DMA = {(2, 4, 8, 4, 2, 8, 2): "256x256,K64,S2", (4, 2, 4, 4, 3, 8, 2): "256x128,K64,S3", (2, 4, 4, 4, 3, 8, 2): "128x256,K64,S3",
+       (2, 4, 8, 4, 4, 4, 2): "256x256,K32,S4", (4, 2, 4, 4, 3, 4, 4): "256x128,K32,S3,x2", (2, 4, 4, 4, 3, 4, 4): "128x256,K32,S3,x2",
+       (1, 8, 4, 4, 2, 4, 4): "64x512,K32,S2,x2"}
+
+
+def family(name):
+    m = re.search(r"conv_igemm_dma_kernel<([\d, ]+)>", name)
+    if m:
+        return "conv_igemm_dma<f16,%s>" % DMA.get(tuple(int(v) for v in m.group(1).split(",")), m.group(1))
+    m = re.search(r"conv_first_kernelI(DF16_|f)Li(\d+)", name)
+    if m:
+        return "conv_first<%s,%s>" % ("f16" if m.group(1) == "DF16_" else "f32", m.group(2))
+    m = re.search(r"conv_igemm_kernelI(DF16_|f)Li(\d)ELi(\d)ELi(\d)ELi(\d)ELb([01])", name)
+    if m:
+        n = {(2, 2): 128, (1, 4): None}[(int(m.group(2)), int(m.group(3)))]
+        if n is None:
+            n = 64 if m.group(4) == "4" else 32
+        return "conv_igemm<%s,N%d,%s>" % ("f16" if m.group(1) == "DF16_" else "f32", n, "perchunk" if m.group(6) == "1" else "uniform")
+    return None
+
+
+acc = defaultdict(lambda: defaultdict(list))
+for f in sorted(glob.glob(os.path.join(root, "pass*", "*counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        fam = family(r["Kernel_Name"])
+        if fam and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            acc[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
+res = {}
+for fam, c in acc.items():
+    fetch = 2.0 * 1024 * sum(c.get("FETCH_SIZE", [0])) / max(1, len(c.get("FETCH_SIZE", [0])))
+    write = 1024.0 * sum(c.get("WRITE_SIZE", [0])) / max(1, len(c.get("WRITE_SIZE", [0])))
+    res[fam] = {"hbm_bytes_per_launch": round(fetch + write), "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
+                "launches_sampled": len(c.get("FETCH_SIZE", []))}
+prev = json.load(open(out_path)) if os.path.exists(out_path) else {}
+prev[workload] = res
+prev["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only), averaged over the launches of each "
+                 "kernel family incl. the small calibration/autotune launches; FETCH_SIZE x2 per the gfx950 correction")
+json.dump(prev, open(out_path, "w"), indent=1, sort_keys=True)
+for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+    print("%-44s fetch %8.1f MB  write %8.1f MB  (n=%d)" % (k, v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6, v["launches_sampled"]))
