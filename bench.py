@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="v3-608-b32-fp16", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--autotune", action="store_true", help="time every conv tile per layer on the device first (default: built-in rules)")
     ap.add_argument("--threshold", type=float, default=0.5)
     ap.add_argument("--iou-threshold", type=float, default=0.6)
     ap.add_argument("--dump-kernels", default=None, help="write the per-kernel timing table (JSON) here")
@@ -130,7 +130,7 @@ def main():
     from tensorflow_yolo_amd.net import synth
     # two different resident input batches, alternated, so no step re-reads the previous step's input
     xs = [torch.from_numpy(synth.synthetic_input(batch, size, size, 3, seed=1000 + 17 * rank + i)).to(dev) for i in range(2)]
-    if not args.no_autotune:
+    if args.autotune:
         eng.autotune(xs[0])     # per-layer conv tile choice, timed on this device (outside the timed region)
     from tensorflow_yolo_amd.net import dist as ydist
 

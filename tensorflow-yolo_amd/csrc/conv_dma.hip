@@ -241,20 +241,28 @@ bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok) {
     return k.na <= (cout + 127) / 128 * 128 && cout > 64;
 }
 
-int choose_dma_cfg(int M, int cout, int cin_chunks, bool v1_ok) {
+// Default tile per layer.  Rules distilled from on-device autotuning (yolo_net_autotune) of YOLOv3-608 at
+// batch 32 on MI355X (profiles/r01_ablation.md): per round a workgroup costs a fixed ~14-20 us (setup,
+// prologue DMA, epilogue traffic) plus ~1.5 us per 64-deep K tile, so
+//   * wide layers with many pixels run the 2-workgroups-per-CU K32 tiles (fixed costs of one overlap the
+//     other's loop; small tiles also quantise the tail better),
+//   * few pixels + deep K (19x19x512->1024: 184 tiles of 256x256 on 256 CUs) prefer the big tile, whose
+//     steady state is ~13 % faster per K,
+//   * few pixels + shallow K (1x1) take the 256x128 K64 tile, tiny problems the 4-wave kernel.
+int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, bool v1_ok) {
     const char *force = getenv("YOLO_CONV_TILE");
     if (force && *force && dma_cfg_valid(atoi(force), cout, cin_chunks, v1_ok)) return atoi(force);
-    int best = v1_ok ? 0 : -1;
-    double best_t = 1e300;
-    for (int c = 0; c < kNumCfgs; ++c) {
-        const DmaCfg &k = kCfgs[c];
-        if (!dma_cfg_valid(c, cout, cin_chunks, v1_ok)) continue;
-        const long long blocks = ((long long)M + k.nb - 1) / k.nb * ((cout + k.na - 1) / k.na);
-        const long long rounds = (blocks + 256LL * k.slots_per_cu - 1) / (256LL * k.slots_per_cu);
-        const double t = (double)rounds * k.na * k.nb * k.slots_per_cu / k.rate;
-        if (t < best_t) { best_t = t; best = c; }
-    }
-    return best;
+    auto ok = [&](int c) { return dma_cfg_valid(c, cout, cin_chunks, v1_ok); };
+    const int fallback = v1_ok ? 0 : -1;
+    const int k64 = taps * cin_chunks / 8;              // 64-deep K tiles
+    if (cout <= 64) return ok(7) && M >= 8192 ? 7 : fallback;
+    const bool narrow = cout <= 128;
+    const int x2 = narrow ? 6 : 5, k64tile = narrow ? 3 : 2;
+    const long long work = (long long)M * ((cout + 127) / 128);     // 128-wide column blocks x pixels
+    if (work < 16384) return fallback;                  // < ~128 small tiles: not enough to fill the chip
+    if (M >= 24576) return ok(x2) ? x2 : ok(k64tile) ? k64tile : fallback;
+    if (!narrow && k64 >= 36 && ok(1)) return 1;
+    return ok(k64tile) ? k64tile : ok(x2) ? x2 : fallback;
 }
 
 int dma_num_cfgs() { return kNumCfgs; }
