@@ -241,28 +241,47 @@ bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok) {
     return k.na <= (cout + 127) / 128 * 128 && cout > 64;
 }
 
-// Default tile per layer.  Rules distilled from on-device autotuning (yolo_net_autotune) of YOLOv3-608 at
-// batch 32 on MI355X (profiles/r01_ablation.md): per round a workgroup costs a fixed ~14-20 us (setup,
-// prologue DMA, epilogue traffic) plus ~1.5 us per 64-deep K tile, so
-//   * wide layers with many pixels run the 2-workgroups-per-CU K32 tiles (fixed costs of one overlap the
-//     other's loop; small tiles also quantise the tail better),
-//   * few pixels + deep K (19x19x512->1024: 184 tiles of 256x256 on 256 CUs) prefer the big tile, whose
-//     steady state is ~13 % faster per K,
-//   * few pixels + shallow K (1x1) take the 256x128 K64 tile, tiny problems the 4-wave kernel.
-int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, bool v1_ok) {
+// Default tile per layer: a cost model calibrated on MI355X (profiles/r01_ablation.md).  A launch runs
+// ceil(workgroups / resident slots) rounds; a round costs `a` microseconds per 64-deep K tile (MFMA +
+// DMA of the tile) plus a fixed `f` (setup, prologue DMA latency, epilogue traffic; ~30 % less without a
+// residual to read).  The constants reproduce the measured layer times of YOLOv3-608/416 and YOLOv2-416
+// within ~10 %, e.g. 13x13x512->1024 at batch 16: 124 us predicted on 256x256 (123 measured, 44
+// workgroups on 256 CUs) vs 71 us on 256x128,K64 (75 measured).  yolo_net_autotune replaces the model by
+// on-device timing when asked.
+struct TileCost { float a_shared, a_alone, f; };   // us per K64 tile (CU shared by two workgroups / alone), fixed us per round
+static const TileCost kCost[] = {
+    {1.14f, 0.82f, 9.0f},       // 0: 4-wave 128x128, two per CU
+    {1.45f, 1.45f, 20.0f},      // 1: 256x256 K64 S2
+    {0.82f, 0.82f, 12.0f},      // 2: 256x128 K64 S3
+    {0.82f, 0.82f, 12.0f},      // 3: 128x256 K64 S3
+    {1.47f, 1.47f, 20.0f},      // 4: 256x256 K32 S4
+    {1.75f, 1.30f, 8.0f},       // 5: 256x128 K32 S3, two per CU
+    {1.75f, 1.30f, 8.0f},       // 6: 128x256 K32 S3, two per CU
+    {0.0f, 0.0f, 0.0f},         // 7: 64x512 (bandwidth-bound narrow layers: chosen by rule)
+};
+
+int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok) {
     const char *force = getenv("YOLO_CONV_TILE");
     if (force && *force && dma_cfg_valid(atoi(force), cout, cin_chunks, v1_ok)) return atoi(force);
-    auto ok = [&](int c) { return dma_cfg_valid(c, cout, cin_chunks, v1_ok); };
     const int fallback = v1_ok ? 0 : -1;
-    const int k64 = taps * cin_chunks / 8;              // 64-deep K tiles
-    if (cout <= 64) return ok(7) && M >= 8192 ? 7 : fallback;
-    const bool narrow = cout <= 128;
-    const int x2 = narrow ? 6 : 5, k64tile = narrow ? 3 : 2;
-    const long long work = (long long)M * ((cout + 127) / 128);     // 128-wide column blocks x pixels
-    if (work < 16384) return fallback;                  // < ~128 small tiles: not enough to fill the chip
-    if (M >= 24576) return ok(x2) ? x2 : ok(k64tile) ? k64tile : fallback;
-    if (!narrow && k64 >= 36 && ok(1)) return 1;
-    return ok(k64tile) ? k64tile : ok(x2) ? x2 : fallback;
+    if (cout <= 64) return dma_cfg_valid(7, cout, cin_chunks, v1_ok) && M >= 8192 ? 7 : fallback;
+    const double k64 = taps * cin_chunks / 8.0;         // 64-deep K tiles
+    int best = fallback;
+    double best_t = 1e300;
+    for (int c = 0; c < 7; ++c) {
+        if (!dma_cfg_valid(c, cout, cin_chunks, v1_ok)) continue;
+        const DmaCfg &k = kCfgs[c];
+        const long long blocks = ((long long)M + k.nb - 1) / k.nb * ((cout + k.na - 1) / k.na);
+        const long long slots = 256LL * k.slots_per_cu;
+        // one workgroup per CU: whole rounds; two per CU: the dispatcher back-fills, the tail costs ~half a round
+        double rounds;
+        if (k.slots_per_cu == 1) rounds = (double)((blocks + slots - 1) / slots);
+        else rounds = blocks <= slots ? 1.0 : (double)blocks / slots + 0.5;
+        const double a = blocks <= 256 ? kCost[c].a_alone : kCost[c].a_shared;
+        const double t = rounds * (k64 * a + kCost[c].f * (has_res ? 1.0 : 0.7));
+        if (t < best_t) { best_t = t; best = c; }
+    }
+    return best;
 }
 
 int dma_num_cfgs() { return kNumCfgs; }

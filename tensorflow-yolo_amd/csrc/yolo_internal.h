@@ -141,7 +141,7 @@ struct NmsParams {
 hipError_t launch_conv(const ConvParams &p, int dtype, int cfg, bool perchunk, hipStream_t s);
 // conv_dma.hip: 8-wave LDS-DMA kernel for the heavy fp16 layers.  choose_dma_cfg returns 0 when the
 // 4-wave kernel of conv.hip should run, else the tile id for launch_conv_dma.
-int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, bool v1_ok);   // -1: no DMA tile and no 4-wave kernel fits
+int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok);   // -1: no DMA tile and no 4-wave kernel fits
 bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok);
 int dma_cfg_bkc(int cfg);
 hipError_t launch_conv_dma(const ConvParams &p, int cfg, hipStream_t s);
