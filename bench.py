@@ -69,7 +69,11 @@ def cpu_baseline(kind, size, w, anchors, ncls, budget_s=20.0):
     net = cls.create_network(np.reshape(anchors, [-1, 2]), names, False, input_shape=(size, size, 3))
     L = to_oracle(net)
     Wd = forward_ref.parse_darknet_weights(L, w)
-    cores = torch.get_num_threads()
+    # MKL-DNN convs on the 128-core GPU host peak at ~32 threads (16: 3.3, 32: 4.0, 64: 2.2, 128: 0.96 images/s,
+    # tools/cpu_threads_probe.py); more threads only add contention, so the baseline uses its best setting.
+    default_threads = torch.get_num_threads()
+    cores = max(1, min(32, default_threads))
+    torch.set_num_threads(cores)
     chunk = 2
     x = synth.synthetic_input(chunk, size, size, 3, seed=123)
 
@@ -90,6 +94,7 @@ def cpu_baseline(kind, size, w, anchors, ncls, budget_s=20.0):
         dt = time.perf_counter() - t0
         if dt > budget_s or n >= 64:
             break
+    torch.set_num_threads(default_threads)
     return {"value": round(n / dt, 3), "unit": "images/sec", "cores": int(cores), "kind": "port",
             "sample": "%d images %dx%d, CPU oracle (torch-CPU fp32 restatement of the reference's TF path + NumPy decode/NMS), "
                       "%.1f s" % (n, size, size, dt)}

@@ -199,13 +199,13 @@ bool dma_eligible(const yolo_net *net, const Kernel &k) {
 // tile 0 = the 4-wave kernel of conv.hip with the planner's cfg (always available)
 bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile) {
     if (tile == 0) return true;
-    return dma_eligible(net, k) && dma_cfg_valid(tile, k.cout, k.cpt, true);
+    return dma_eligible(net, k) && dma_cfg_valid(tile, k.cout, k.cpt, true, k.ksize, k.stride, k.in.W);
 }
 
 // tile < 0: heuristic (choose_dma_cfg); 0: 4-wave kernel of conv.hip; > 0: conv_dma.hip tile id
 hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParams &p, int tile, hipStream_t s) {
     if (!dma_eligible(net, k)) tile = 0;
-    else if (tile < 0) tile = choose_dma_cfg(p.M, k.cout, k.cpt, p.taps, k.has_res, true);
+    else if (tile < 0) tile = choose_dma_cfg(p.M, k.cout, k.cpt, p.taps, k.has_res, true, k.stride, k.in.W);
     return tile > 0 ? launch_conv_dma(p, tile, s) : launch_conv(p, net->opt.dtype, k.cfg, k.perchunk != 0, s);
 }
 
@@ -377,7 +377,7 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         out->weight_bytes = (double)k.cout * k.ksize * k.ksize * k.cin * net->esize + 4.0 * k.cout;
         int tile = 0;       // which kernel runs at max_batch (bench.py runs at max_batch)
         if (dma_eligible(net, k))
-            tile = k.tile >= 0 ? k.tile : choose_dma_cfg(net->opt.max_batch * li.H * li.W, k.cout, k.cpt, k.ksize * k.ksize, k.has_res, true);
+            tile = k.tile >= 0 ? k.tile : choose_dma_cfg(net->opt.max_batch * li.H * li.W, k.cout, k.cpt, k.ksize * k.ksize, k.has_res, true, k.stride, k.in.W);
         if (tile > 0) {
             out->variant = 8 + tile;
             snprintf(out->name, sizeof out->name, "conv_igemm_dma<f16,%s>", dma_cfg_name(tile));

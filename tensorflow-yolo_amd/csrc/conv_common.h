@@ -38,7 +38,9 @@ __device__ __forceinline__ float4v mma_chunk<float>(const uint4v &a, const uint4
 // (cbase ..) of pixel (m_wave + 16 b + fr).  bias (folded BN) -> leaky 0.1 (layers.py:6,51) ->
 // + residual (shortcut, layers.py:102: no activation after the add) -> store through the output
 // index map (identity / nearest-upsample x2 layers.py:115 / block-major reorg layers.py:92-96).
-template <typename T, int TM, int TP>
+// PADQ (conv_tap.hip): the pixel index is a position q of the padded-linear grid [n][y <= H][x <= W] (one shared
+// zero row / column between image rows and images); pad positions are computed but never stored.
+template <typename T, int TM, int TP, bool PADQ = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, const float4v (&acc)[TM][TP], int cbase, int m_wave, int fr) {
     constexpr int CH = 4 * TM;
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -51,9 +53,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, const float4v
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
         const int m = m_wave + b * 16 + fr;
-        if (m >= p.M) continue;
-        const int n = m / p.HoWo;
-        const int rem = m - n * p.HoWo;
+        int n, rem, oy, ox;
+        if (PADQ) {
+            if (m >= p.Mq) continue;
+            n = m / p.qHW;
+            const int r = m - n * p.qHW;
+            oy = r / p.qW;
+            ox = r - oy * p.qW;
+            if (ox == p.Wo || oy == p.Ho) continue;
+            rem = oy * p.Wo + ox;
+        } else {
+            if (m >= p.M) continue;
+            n = m / p.HoWo;
+            rem = m - n * p.HoWo;
+            oy = rem / p.Wo;
+            ox = rem - oy * p.Wo;
+        }
         float v[CH];
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -78,7 +93,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, const float4v
                 for (int i = 0; i < nvalid; ++i) v[i] += (float)rp[i];
             }
         }
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         long long off[4];
         int npos = 1;
         if (p.outmode == OUT_NORMAL) {

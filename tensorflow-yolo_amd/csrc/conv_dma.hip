@@ -227,16 +227,20 @@ static const DmaCfg kCfgs[] = {
     {256, 128, 2, 1.30f, "256x128,K32,S3,x2", 4},  // 5: 72 KiB LDS, <=128 VGPRs: two workgroups per CU
     {128, 256, 2, 1.30f, "128x256,K32,S3,x2", 4},  // 6
     {64, 512, 2, 1.00f, "64x512,K32,S2,x2", 4},    // 7: narrow early layers (Cout <= 64), bandwidth-bound
+    {128, 256, 2, 1.00f, "128x256,tap9,x2", 4},        // 8: conv_tap.hip, 3x3/1 only: input patch loaded once for the 9 taps
+    {256, 256, 1, 1.00f, "256x256,tap9", 4},           // 9
 };
-static const int kNumCfgs = 8;
+static const int kNumCfgs = 10;
+static const int kFirstTapCfg = 8;
 
 // Pick the block tile that minimises rounds x tile time on 256 CUs (tail quantisation matters:
 // e.g. 38x38x512 at batch 32 is 362 tiles of 256x256 = 2 rounds at 71 % but 722 of 256x128 = 3 at 94 %).
-bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok) {
+bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok, int ksize, int stride, int W) {
     if (cfg == 0) return v1_ok;
     if (cfg < 0 || cfg >= kNumCfgs) return false;
     const DmaCfg &k = kCfgs[cfg];
     if (cin_chunks % k.bkc) return false;
+    if (cfg >= kFirstTapCfg && (ksize != 3 || stride != 1 || !conv_tap_fits(cfg - kFirstTapCfg, W))) return false;
     if (k.na == 64) return cout <= 64;
     return k.na <= (cout + 127) / 128 * 128 && cout > 64;
 }
@@ -258,20 +262,25 @@ static const TileCost kCost[] = {
     {1.75f, 1.30f, 8.0f},       // 5: 256x128 K32 S3, two per CU
     {1.75f, 1.30f, 8.0f},       // 6: 128x256 K32 S3, two per CU
     {0.0f, 0.0f, 0.0f},         // 7: 64x512 (bandwidth-bound narrow layers: chosen by rule)
+    {1.30f, 1.00f, 8.0f},       // 8: 128x256 tap reuse, two per CU
+    {1.09f, 1.09f, 22.0f},      // 9: 256x256 tap reuse
 };
 
-int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok) {
+int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W) {
+    const int ksize = taps == 9 ? 3 : 1;
     const char *force = getenv("YOLO_CONV_TILE");
-    if (force && *force && dma_cfg_valid(atoi(force), cout, cin_chunks, v1_ok)) return atoi(force);
+    if (force && *force && dma_cfg_valid(atoi(force), cout, cin_chunks, v1_ok, ksize, stride, W)) return atoi(force);
     const int fallback = v1_ok ? 0 : -1;
-    if (cout <= 64) return dma_cfg_valid(7, cout, cin_chunks, v1_ok) && M >= 8192 ? 7 : fallback;
+    if (cout <= 64) return dma_cfg_valid(7, cout, cin_chunks, v1_ok, ksize, stride, W) && M >= 8192 ? 7 : fallback;
     const double k64 = taps * cin_chunks / 8.0;         // 64-deep K tiles
     int best = fallback;
     double best_t = 1e300;
-    for (int c = 0; c < 7; ++c) {
-        if (!dma_cfg_valid(c, cout, cin_chunks, v1_ok)) continue;
+    for (int c = 0; c < kNumCfgs; ++c) {
+        if (c == 7 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
         const DmaCfg &k = kCfgs[c];
-        const long long blocks = ((long long)M + k.nb - 1) / k.nb * ((cout + k.na - 1) / k.na);
+        // tap-reuse tiles walk the padded position grid: (H+1)(W+1) positions per image (square maps assumed here)
+        const long long Meff = c >= kFirstTapCfg ? (long long)M * (W + 1) * (W + 1) / ((long long)W * W) : M;
+        const long long blocks = (Meff + k.nb - 1) / k.nb * ((cout + k.na - 1) / k.na);
         const long long slots = 256LL * k.slots_per_cu;
         // one workgroup per CU: whole rounds; two per CU: the dispatcher back-fills, the tail costs ~half a round
         double rounds;
@@ -303,6 +312,16 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
     const long long blocks = ((long long)p.M + k.nb - 1) / k.nb * p.n_tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     p.n_blocks = (int)blocks;
+    if (cfg >= kFirstTapCfg) {      // padded-linear position grid: one shared pad column per row, one pad row per image
+        p.qW = p.W + 1;
+        p.qHW = (p.H + 1) * (p.W + 1);
+        const long long mq = (long long)(p.M / p.HoWo) * p.qHW;
+        const long long qblocks = (mq + k.nb - 1) / k.nb * p.n_tiles_n;
+        if (qblocks <= 0 || qblocks > 0x7fffffffLL) return hipErrorInvalidValue;
+        p.Mq = (int)mq;
+        p.n_blocks = (int)qblocks;
+        return launch_conv_tap(p, cfg - kFirstTapCfg, s);
+    }
     const dim3 grid((unsigned)blocks), block(512);
     switch (cfg) {
     case 1: hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 8, 4, 2, 8, 2>), grid, block, 0, s, p); break;

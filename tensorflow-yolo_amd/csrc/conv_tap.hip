@@ -1,0 +1,215 @@
+// 3x3 / stride-1 implicit-GEMM conv (fp16) with TAP REUSE of the pixel operand.
+//
+// Why: the LDS-DMA kernels of conv_dma.hip fetch the pixel tile once PER TAP (im2col on the fly), and their K
+// loop is bound by the L2 -> LDS path: 20 TB/s chip-wide = ~78 GB/s per CU measured with the MFMAs switched
+// off (profiles/r01_ablation.md; the guide's L2-served gather-into-LDS figure is 66-73 GB/s per CU), against
+// ~85-130 flop/byte of those tiles.  Here the input patch of a block is loaded ONCE per 32-channel slice and
+// all nine taps read their MFMA B operand from it at a row offset, so a 128-cout x 256-pixel block moves
+// 8 KiB of weights per tap + ~26 KiB of pixels per nine taps: ~190 flop/byte, 2.2x fewer L2 -> LDS bytes.
+//
+// Pixel indexing: positions q of a PADDED-LINEAR grid [n][y in 0..H][x in 0..W] -- one shared pad column after
+// every image row and one shared pad row after every image.  Tap (kh, kw) of position q is position
+// q + (kh-1)(W+1) + (kw-1), for every q, so a block owning NB consecutive positions keeps the NB + 2W + 4
+// positions around them in LDS (64-byte rows = 32 channels) and tap t reads rows shifted by kh (W+1) + kw.
+// Pad positions are filled with zeros by the LDS-DMA range check (per-lane source offset = invalid) -- this is
+// the conv's zero padding -- and as OUTPUT positions they are computed and dropped in the epilogue
+// ((H+1)(W+1)/(HW) - 1 wasted MFMA work: 2.6 % at 76x76, 10.8 % at 19x19).
+//
+// LDS swizzle of the patch: logical 16-byte chunk c of row R sits at chunk c ^ (2 * ((R >> 2) & 1)).  Unlike
+// the table swizzle of the weight tile this one stays conflict-free for ds_read_b128 under ANY row shift: the
+// hardware services lanes {0-3, 12-15, 20-27} (k-chunk q for fragment rows 0-3, 12-15, chunk q^1 for rows
+// 4-11) together, the four rows of one residue class mod 4 are consecutive values of R >> 2, and
+// {s(u), s(u+1)^1, s(u+2)^1, s(u+3)} is a permutation of 0..3 for s(u) = 2 (u & 1) and every u.
+//
+// K loop: for each 32-channel slice c: for tap 0..8 (unrolled): weights of (tap, c) come through a 3-slot
+// LDS-DMA ring (slot = tap % 3), the patch of slice c+1 is fetched into the other patch buffer during the taps
+// of slice c.  One barrier per tap; vmcnt waits are counted so that the patch may stay in flight for three taps.
+#include "conv_common.h"
+#include <type_traits>
+
+namespace yolo {
+
+namespace {
+
+typedef __attribute__((address_space(3))) void tap_lds_void;
+
+// voff: per-lane byte offset (loop invariant, range-checked: an invalid offset writes zeros); soff: wave-uniform
+// byte offset of the K position, added by the hardware after the range check -> no per-tap address registers.
+__device__ __forceinline__ void tap_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char *lds_dst, uint32_t voff, uint32_t soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (tap_lds_void *)lds_dst, 16, voff, soff, 0, 0);
+#else
+    (void)rsrc; (void)lds_dst; (void)voff; (void)soff;
+#endif
+}
+
+template <int N>
+__device__ __forceinline__ void tap_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ int tap_swz_w(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }   // weight tile: {0,2,3,1}[(r>>2)&3]
+
+}  // namespace
+
+// 8 waves = WM x WN; a wave owns TM*16 couts x TP*16 positions; PRG = 16-row groups of one patch buffer.
+template <int WM, int WN, int TM, int TP, int PRG, int OCC>
+__global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams p) {
+    typedef _Float16 T;
+    constexpr int NW = 8;
+    constexpr int S = 3;                    // weight ring slots (9 taps per slice: slot = tap % 3)
+    constexpr int ROWB = 64;
+    constexpr int NA = WM * TM * 16;
+    constexpr int NB = WN * TP * 16;
+    constexpr int JA = NA / (16 * NW);      // weight DMA wave-instructions per wave per tap
+    constexpr int JP = (PRG + NW - 1) / NW; // patch DMA wave-instructions per wave per slice
+    constexpr int CH = 4 * TM;
+    constexpr int A_BYTES = NA * ROWB;
+    constexpr int P_BYTES = PRG * 1024;
+    constexpr int TRASH = S * A_BYTES + 2 * P_BYTES;    // 1 KiB that absorbs the DMA slots beyond the patch
+    static_assert(WM * WN == NW, "eight waves");
+    static_assert(JA >= 1 && JA * 16 * NW == NA, "weight tile must split evenly over the waves");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[S * A_BYTES + 2 * P_BYTES + 1024];
+    unsigned char *const smemP = smem + S * A_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int bid = xcd_remap(blockIdx.x, p.n_blocks);
+    const int nt = bid % p.n_tiles_n;
+    const int mt = bid / p.n_tiles_n;
+    const int n0 = nt * NA;
+    const int q0 = mt * NB;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wgt), 0, p.wgt_bytes, 0x00020000);
+
+    // ---- DMA geometry ----------------------------------------------------------------------------
+    const int lrow = lane >> 2;
+    uint32_t a_off[JA];
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+        const int r = (j * NW + wave) * 16 + lrow;              // LDS row of the weight tile
+        const int ws = r / (TM * 16), R = r % (TM * 16);
+        const int tm = R >> 4, g4 = (R >> 2) & 3, jj = R & 3;
+        const int ch = ws * (TM * 16) + g4 * CH + 4 * tm + jj;  // the cout that row holds (see conv_epilogue)
+        a_off[j] = (uint32_t)(n0 + ch) * p.wrow_bytes + (uint32_t)(((lane & 3) ^ tap_swz_w(lrow)) << 4);
+    }
+    // patch row R <-> position q0 - (W+2) + R; row group g = j NW + wave
+    uint32_t b_off[JP];
+    int b_dst[JP];
+    const uint32_t csw_p = (uint32_t)(((lane & 3) ^ (((lrow >> 2) & 1) << 1)) << 4);
+#pragma unroll
+    for (int j = 0; j < JP; ++j) {
+        const int g = j * NW + wave;
+        const int q = q0 - (p.qW + 1) + g * 16 + lrow;
+        bool ok = g < PRG && q >= 0 && q < p.Mq;
+        const int qq = ok ? q : 0;
+        const int n = qq / p.qHW;
+        const int r = qq - n * p.qHW;
+        const int y = r / p.qW;
+        const int x = r - y * p.qW;
+        ok = ok && x < p.W && y < p.H;
+        const long long e = (long long)n * p.in_img_stride + ((long long)y * p.W + x) * p.in_ld + p.in_coff;
+        b_off[j] = ok ? (uint32_t)(e * 2) + csw_p : YOLO_INVALID_OFF;
+        b_dst[j] = g < PRG ? g * 1024 : TRASH - S * A_BYTES;    // relative to smemP (wave-uniform)
+    }
+
+    const int C = p.cin_chunks >> 2;        // 32-channel slices
+    const int KT = 9 * C;
+    auto issue_patch = [&](int c, int buf) {
+        const uint32_t koff = (uint32_t)c * ROWB;
+#pragma unroll
+        for (int j = 0; j < JP; ++j) {
+            unsigned char *dst = smemP + b_dst[j] + (b_dst[j] < 2 * P_BYTES ? buf * P_BYTES : 0);
+            tap_dma16(rs_in, dst, b_off[j], koff);
+        }
+    };
+    auto issue_weights = [&](int tap, int c, int slot) {
+        const uint32_t ka = (uint32_t)(tap * p.cin_chunks + 4 * c) * 16;
+#pragma unroll
+        for (int j = 0; j < JA; ++j) tap_dma16(rs_w, smem + slot * A_BYTES + (j * NW + wave) * 1024, a_off[j], ka);
+    };
+
+    float4v acc[TM][TP];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int a_frag = (wm * TM * 16 + fr) * ROWB + (((fq ^ tap_swz_w(fr)) & 3) << 4);
+    const int rb = wn * TP * 16 + fr;       // patch row of this lane's position for tap (0, 0)
+
+    auto compute = [&](int slot, int buf, int shift) {
+        const unsigned char *A = smem + slot * A_BYTES + a_frag;
+        const int R = rb + shift;
+        const unsigned char *B = smemP + buf * P_BYTES + (R << 6) + ((fq << 4) ^ ((R & 4) << 3));
+        uint4v fa[TM], fb[TP];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const uint4v *>(A + a * 16 * ROWB);
+#pragma unroll
+        for (int b = 0; b < TP; ++b) fb[b] = *reinterpret_cast<const uint4v *>(B + b * 16 * ROWB);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TP; ++b) acc[a][b] = mma_chunk<T>(fa[a], fb[b], acc[a][b]);
+    };
+
+    // ---- prologue: patch of slice 0, weights of taps 0 and 1 --------------------------------------
+    issue_patch(0, 0);
+    issue_weights(0, 0, 0);
+    issue_weights(1, 0, 1);
+
+    // one 32-channel slice; the patch buffer index is a compile-time constant (LDS immediates, no address registers)
+    auto run_slice = [&](int c, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        const bool more = c + 1 < C;        // a next slice exists: its patch is fetched during this one
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // Wait for the weights of this tap.  Issue order per tap: weights(tap+2), then (tap 0 only) the next
+            // patch; younger than weights(tap) are weights(tap+1) and, at taps 1 and 2, that patch.
+            const bool last = !more && tap == 8;
+            if (last) tap_wait_vm<0>();
+            else if (more && (tap == 1 || tap == 2)) tap_wait_vm<JA + JP>();
+            else tap_wait_vm<JA>();
+            __builtin_amdgcn_s_barrier();
+            {   // weights two taps ahead
+                const int t2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;
+                const int c2 = tap + 2 < 9 ? c : c + 1;
+                if (c2 < C) issue_weights(t2, c2, (tap + 2) % S);
+            }
+            if (tap == 0 && more) issue_patch(c + 1, buf ^ 1);
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            compute(tap % S, buf, kh * p.qW + kw);
+        }
+    };
+    for (int c = 0; c < C; c += 2) {
+        run_slice(c, std::integral_constant<int, 0>());
+        if (c + 1 < C) run_slice(c + 1, std::integral_constant<int, 1>());
+    }
+    (void)KT;
+    conv_epilogue<T, TM, TP, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
+}
+
+// variant 0: 128 couts x 256 positions, two workgroups per CU (W <= 78); variant 1: 256 x 256, one per CU
+bool conv_tap_fits(int variant, int W) {
+    const int prg = variant == 0 ? 26 : 26;
+    return 256 + 2 * W + 4 <= prg * 16;
+}
+
+hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
+    if (p.ksize != 3 || p.stride != 1 || p.pad != 1 || p.Ho != p.H || p.Wo != p.W || (p.cin_chunks & 3) || !conv_tap_fits(variant, p.W))
+        return hipErrorInvalidValue;
+    const dim3 grid((unsigned)p.n_blocks);
+    switch (variant) {
+    case 0: hipLaunchKernelGGL((conv3x3_tap_kernel<2, 4, 4, 4, 26, 4>), grid, dim3(512), 0, s, p); break;
+    case 1: hipLaunchKernelGGL((conv3x3_tap_kernel<2, 4, 8, 4, 26, 2>), grid, dim3(512), 0, s, p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace yolo

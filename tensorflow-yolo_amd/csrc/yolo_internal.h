@@ -65,6 +65,7 @@ struct ConvParams {
     int n_tiles_n, n_blocks;
     int stagger;               // conv_dma x2 tiles: initial sleep (x8128 cycles) of the second resident workgroup
     int dbg;                   // experiment flags (YOLO_CONV_DBG): 1 skip steady-state DMA, 2 skip MFMA phase
+    int qW, qHW, Mq;           // conv_tap.hip: padded-linear pixel grid, row stride W+1, image stride (H+1)(W+1), total
 };
 
 struct PrepParams {            // float32 NHWC [B,H,W,C] -> T NHWC [B,H,W,Cpad], zero fill
@@ -141,10 +142,12 @@ struct NmsParams {
 hipError_t launch_conv(const ConvParams &p, int dtype, int cfg, bool perchunk, hipStream_t s);
 // conv_dma.hip: 8-wave LDS-DMA kernel for the heavy fp16 layers.  choose_dma_cfg returns 0 when the
 // 4-wave kernel of conv.hip should run, else the tile id for launch_conv_dma.
-int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok);   // -1: no DMA tile and no 4-wave kernel fits
-bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok);
+int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W);   // -1: no DMA tile and no 4-wave kernel fits
+bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok, int ksize, int stride, int W);
 int dma_cfg_bkc(int cfg);
 hipError_t launch_conv_dma(const ConvParams &p, int cfg, hipStream_t s);
+hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s);       // conv_tap.hip: 3x3/1 with tap reuse
+bool conv_tap_fits(int variant, int W);
 const char *dma_cfg_name(int cfg);
 int dma_num_cfgs();
 int dma_cfg_na(int cfg);

@@ -195,6 +195,55 @@ def test_errors_are_reported():
         eng.load_weights(np.zeros(5, np.float32))
 
 
+@pytest.mark.parametrize("tile", [8, 9])
+def test_tap_reuse_tile_configs(tile, monkeypatch):
+    """tap-reuse tiles of conv_tap.hip (3x3/1 only: patch of 1, 2, 4 and 6 channel slices, image borders inside a
+    block, position tail; the other layers fall back to the default choice) forced through YOLO_CONV_TILE: K-stage counts 1, 2 (shorter than the
+    LDS ring), 4, 9 (odd), 18, 36, 54 and 72, residual, stride 2, M tails, Cout 255 head"""
+    monkeypatch.setenv("YOLO_CONV_TILE", str(tile))
+    g = new_graph(21, 19, 3)
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))                  # 1  first-layer kernel
+    g.append(PL.conv2d_bn_act(g[-1].out, 128, 1, 1))                 # 2  Cin 32 1x1: 1 stage
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 3, 2))                  # 3  (narrow: other kernel)
+    g.append(PL.conv2d_bn_act(g[-1].out, 128, 1, 1))                 # 4  Cin 64 1x1: 2 stages
+    g.append(PL.conv2d_bn_act(g[-1].out, 192, 1, 1))                 # 5  Cin 128 1x1: 4 stages, Cout tail
+    g.append(PL.conv2d_bn_act(g[-1].out, 128, 3, 1))                 # 6  Cin 192 3x3: 54 stages
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 1, 1))                  # 7
+    g.append(PL.conv2d_bn_act(g[-1].out, 128, 3, 1))                 # 8  Cin 32 3x3: 9 stages
+    g.append(PL.shortcut(g[-1].out, g[-3].out))                      # 9  fused residual
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 1, 1))                  # 10
+    g.append(PL.conv2d_bn_act(g[-1].out, 256, 3, 2))                 # 11 Cin 64 3x3/2: 18 stages
+    g.append(PL.conv2d_bn_act(g[-1].out, 128, 1, 1))                 # 12 8 stages
+    g.append(PL.conv2d_bn_act(g[-1].out, 256, 3, 1))                 # 13 36 stages
+    g.append(PL.shortcut(g[-1].out, g[-3].out))                      # 14
+    g.append(PL.conv2d_bn_act(g[-1].out, 512, 3, 1))                 # 15 72 stages, two cout tiles
+    g.append(PL.conv2d_bn_act(g[-1].out, 255, 1, 1, use_batch_normalization=False, activation_fn="linear"))   # 16 head
+    x = synth.synthetic_input(5, 21, 19, 3, seed=12)
+    eng = check_graph(g, x, "fp16", seed=4, read=(2, 4, 6, 9, 11, 14, 15))
+    names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
+    assert "tap9" in names, names
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 19, 512, 256), (3, 38, 38, 64, 128), (1, 76, 76, 128, 256), (2, 7, 78, 32, 128)])
+@pytest.mark.parametrize("tile", [8, 9])
+def test_tap_reuse_conv_shapes(shape, tile, monkeypatch):
+    """conv_tap.hip on the feature-map sizes of YOLOv3-608 (19, 38, 76), the widest row it takes (78) and a
+    residual input: blocks span image rows, images and the end of the batch"""
+    monkeypatch.setenv("YOLO_CONV_TILE", str(tile))
+    B, H, W, cin, cout = shape
+    g = new_graph(H, W, cin)
+    g.append(PL.conv2d_bn_act(g[-1].out, cout, 3, 1))
+    g.append(PL.conv2d_bn_act(g[-1].out, cin, 1, 1))
+    g.append(PL.conv2d_bn_act(g[-1].out, cout, 3, 1))
+    g.append(PL.shortcut(g[-1].out, g[-3].out))
+    g.append(PL.max_pool2d(g[-1].out, 2, stride=1))
+    x = synth.synthetic_input(B, H, W, cin, seed=21)
+    eng = check_graph(g, x, "fp16", seed=5, read=(1, 4))
+    names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
+    if tile == 8 or cout >= 256:       # the 256-cout tile is not offered to 128-cout layers
+        assert "tap9" in names, names
+
+
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
 def test_every_dma_tile_config(tile, monkeypatch):
     """each LDS-DMA tile shape of conv_dma.hip, forced through YOLO_CONV_TILE (read at every launch; a tile

@@ -31,9 +31,17 @@ def family(name):
 
 acc = defaultdict(lambda: defaultdict(list))
 for f in sorted(glob.glob(os.path.join(root, "pass*", "*counter_collection.csv"))):
-    for r in csv.DictReader(open(f)):
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE")]
+    if not rows:
+        continue
+    # keep only the launches of the LAST forward pass of the run (between the last two nms_kernel dispatches): the
+    # earlier ones include the small batch-2 calibration net
+    order = sorted({int(r["Dispatch_Id"]): r["Kernel_Name"] for r in rows}.items())
+    nms = [d for d, n in order if "nms_kernel" in n]
+    lo, hi = (nms[-2], nms[-1]) if len(nms) >= 2 else (-1, 1 << 62)
+    for r in rows:
         fam = family(r["Kernel_Name"])
-        if fam and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+        if fam and lo < int(r["Dispatch_Id"]) < hi:
             acc[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for fam, c in acc.items():
@@ -44,7 +52,7 @@ for fam, c in acc.items():
 prev = json.load(open(out_path)) if os.path.exists(out_path) else {}
 prev[workload] = res
 prev["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only), averaged over the launches of each "
-                 "kernel family incl. the small calibration/autotune launches; FETCH_SIZE x2 per the gfx950 correction")
+                 "kernel family inside one forward pass of the named workload; FETCH_SIZE x2 per the gfx950 correction")
 json.dump(prev, open(out_path, "w"), indent=1, sort_keys=True)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
     print("%-44s fetch %8.1f MB  write %8.1f MB  (n=%d)" % (k, v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6, v["launches_sampled"]))
