@@ -46,8 +46,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     const int wm = wave / WN, wn = wave % WN;
 
     const int bid = xcd_remap(blockIdx.x, p.n_blocks);
-    const int nt = bid % p.n_tiles_n;
-    const int mt = bid / p.n_tiles_n;
+    const int mt = (int)fdiv((uint32_t)bid, p.dtiles_n);
+    const int nt = bid - mt * p.n_tiles_n;
     const int n0 = nt * NA;
     const int m0 = mt * NB;
 
@@ -74,9 +74,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
         const int m = m0 + r0 + 32 * i;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        const int n = mm / p.HoWo;
+        const int n = (int)fdiv((uint32_t)mm, p.dHoWo);
         const int rem = mm - n * p.HoWo;
-        const int oy = rem / p.Wo;
+        const int oy = (int)fdiv((uint32_t)rem, p.dWo);
         const int ox = rem - oy * p.Wo;
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
         const long long e = (long long)n * p.in_img_stride + ((long long)iy0 * p.W + ix0) * p.in_ld + p.in_coff;
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
         uint32_t mask = 0;
         if (ok) {
             for (int t = 0; t < p.taps; ++t) {
-                const int kh = t / p.ksize, kw = t - kh * p.ksize;
+                const int kh = p.ksize == 3 ? (t * 11) >> 5 : 0, kw = t - kh * p.ksize;    // ksize is 1 or 3
                 if ((unsigned)(iy0 + kh) < (unsigned)p.H && (unsigned)(ix0 + kw) < (unsigned)p.W) mask |= 1u << t;
             }
         }
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
             tap = kc >> p.cpt_shift;
             koff = (uint32_t)(kc & ((1 << p.cpt_shift) - 1)) * 16;
         } else {
-            tap = kt / p.tiles_per_tap;
+            tap = (int)fdiv((uint32_t)kt, p.dtpt);
             koff = (uint32_t)(kt - tap * p.tiles_per_tap) * 128;
         }
         const int kh = p.ksize == 3 ? (tap * 11) >> 5 : 0;
@@ -182,6 +182,7 @@ static hipError_t launch_cfg(const ConvParams &p0, int cfg, hipStream_t s) {
     const long long blocks = mt * p.n_tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     p.n_blocks = (int)blocks;
+    conv_set_divisors(p, p.tiles_per_tap);
     dim3 grid((unsigned)blocks), block(256);
     switch (cfg) {
     case CFG_N128: hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 4, 4, PC>), grid, block, 0, s, p); break;

@@ -56,17 +56,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, const float4v
         int n, rem, oy, ox;
         if (PADQ) {
             if (m >= p.Mq) continue;
-            n = m / p.qHW;
+            n = (int)fdiv((uint32_t)m, p.dqHW);
             const int r = m - n * p.qHW;
-            oy = r / p.qW;
+            oy = (int)fdiv((uint32_t)r, p.dqW);
             ox = r - oy * p.qW;
             if (ox == p.Wo || oy == p.Ho) continue;
             rem = oy * p.Wo + ox;
         } else {
             if (m >= p.M) continue;
-            n = m / p.HoWo;
+            n = (int)fdiv((uint32_t)m, p.dHoWo);
             rem = m - n * p.HoWo;
-            oy = rem / p.Wo;
+            oy = (int)fdiv((uint32_t)rem, p.dWo);
             ox = rem - oy * p.Wo;
         }
         float v[CH];

@@ -79,8 +79,8 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
     const bool has_a = A_ALL || wave < JA_TOT;     // wave-uniform
 
     const int bid = xcd_remap(blockIdx.x, p.n_blocks);
-    const int nt = bid % p.n_tiles_n;
-    const int mt = bid / p.n_tiles_n;
+    const int mt = (int)fdiv((uint32_t)bid, p.dtiles_n);
+    const int nt = bid - mt * p.n_tiles_n;
     const int n0 = nt * NA;
     const int m0 = mt * NB;
 
@@ -118,9 +118,9 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
         const int m = m0 + (j * 8 + wave) * RPI + lrow;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        const int n = mm / p.HoWo;
+        const int n = (int)fdiv((uint32_t)mm, p.dHoWo);
         const int rem = mm - n * p.HoWo;
-        const int oy = rem / p.Wo;
+        const int oy = (int)fdiv((uint32_t)rem, p.dWo);
         const int ox = rem - oy * p.Wo;
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
         const long long e = (long long)n * p.in_img_stride + ((long long)iy0 * p.W + ix0) * p.in_ld + p.in_coff;
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
         uint32_t mask = 0;
         if (ok) {
             for (int t = 0; t < p.taps; ++t) {
-                const int kh = t / p.ksize, kw = t - kh * p.ksize;
+                const int kh = p.ksize == 3 ? (t * 11) >> 5 : 0, kw = t - kh * p.ksize;    // ksize is 1 or 3
                 if ((unsigned)(iy0 + kh) < (unsigned)p.H && (unsigned)(ix0 + kw) < (unsigned)p.W) mask |= 1u << t;
             }
         }
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
             for (int j = 0; j < JA; ++j)
                 dma16(rs_w, base + j * 8192, a_off[j] + ka);
         }
-        const int tap = kt / tpt;
+        const int tap = (int)fdiv((uint32_t)kt, p.dtpt);
         const uint32_t koff = (uint32_t)(kt - tap * tpt) * ROWB;
         const int kh = p.ksize == 3 ? (tap * 11) >> 5 : 0;
         const int kw = tap - kh * p.ksize;
@@ -312,6 +312,7 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
     const long long blocks = ((long long)p.M + k.nb - 1) / k.nb * p.n_tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     p.n_blocks = (int)blocks;
+    conv_set_divisors(p, p.cin_chunks / k.bkc);
     if (cfg >= kFirstTapCfg) {      // padded-linear position grid: one shared pad column per row, one pad row per image
         p.qW = p.W + 1;
         p.qHW = (p.H + 1) * (p.W + 1);
@@ -320,6 +321,7 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
         if (qblocks <= 0 || qblocks > 0x7fffffffLL) return hipErrorInvalidValue;
         p.Mq = (int)mq;
         p.n_blocks = (int)qblocks;
+        conv_set_divisors(p, p.cin_chunks / k.bkc);
         return launch_conv_tap(p, cfg - kFirstTapCfg, s);
     }
     const dim3 grid((unsigned)blocks), block(512);

@@ -78,8 +78,8 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     const int wm = wave / WN, wn = wave % WN;
 
     const int bid = xcd_remap(blockIdx.x, p.n_blocks);
-    const int nt = bid % p.n_tiles_n;
-    const int mt = bid / p.n_tiles_n;
+    const int mt = (int)fdiv((uint32_t)bid, p.dtiles_n);
+    const int nt = bid - mt * p.n_tiles_n;
     const int n0 = nt * NA;
     const int q0 = mt * NB;
 
@@ -107,9 +107,9 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         const int q = q0 - (p.qW + 1) + g * 16 + lrow;
         bool ok = g < PRG && q >= 0 && q < p.Mq;
         const int qq = ok ? q : 0;
-        const int n = qq / p.qHW;
+        const int n = (int)fdiv((uint32_t)qq, p.dqHW);
         const int r = qq - n * p.qHW;
-        const int y = r / p.qW;
+        const int y = (int)fdiv((uint32_t)r, p.dqW);
         const int x = r - y * p.qW;
         ok = ok && x < p.W && y < p.H;
         const long long e = (long long)n * p.in_img_stride + ((long long)y * p.W + x) * p.in_ld + p.in_coff;
@@ -179,11 +179,11 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
             {   // weights two taps ahead
                 const int t2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;
                 const int c2 = tap + 2 < 9 ? c : c + 1;
-                if (c2 < C) issue_weights(t2, c2, (tap + 2) % S);
+                if (c2 < C && !(p.dbg & 1)) issue_weights(t2, c2, (tap + 2) % S);
             }
-            if (tap == 0 && more) issue_patch(c + 1, buf ^ 1);
+            if (tap == 0 && more && !(p.dbg & 1)) issue_patch(c + 1, buf ^ 1);
             const int kh = tap / 3, kw = tap - 3 * kh;
-            compute(tap % S, buf, kh * p.qW + kw);
+            if (!(p.dbg & 2)) compute(tap % S, buf, kh * p.qW + kw);
         }
     };
     for (int c = 0; c < C; c += 2) {
@@ -191,6 +191,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         if (c + 1 < C) run_slice(c + 1, std::integral_constant<int, 1>());
     }
     (void)KT;
+    if (p.dbg & 4) return;              // experiment flags (YOLO_CONV_DBG): 1 no steady-state DMA, 2 no MFMA phase, 4 no epilogue
     conv_epilogue<T, TM, TP, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
 }
 

@@ -35,10 +35,10 @@ __global__ void __launch_bounds__(256) conv_first_kernel(const FirstParams p) {
     const long long pix = px0 + lane;
     const bool live = pix < p.total;
     const long long pp = live ? pix : p.total - 1;
-    const int ox = (int)(pp % p.W);
-    const long long t = pp / p.W;
-    const int oy = (int)(t % p.H);
-    const long long n = t / p.H;
+    const uint32_t t = fdiv((uint32_t)pp, p.dW);         // p.total < 2^31 (checked by the launcher)
+    const int ox = (int)((uint32_t)pp - t * (uint32_t)p.W);
+    const long long n = fdiv(t, p.dH);
+    const int oy = (int)(t - (uint32_t)n * (uint32_t)p.H);
 
     float acc[COUT];
 #pragma unroll
@@ -95,16 +95,20 @@ __global__ void __launch_bounds__(256) conv_first_kernel(const FirstParams p) {
         const long long gp = px0 + lp;
         if (gp < p.total) {
             const uint4v u = *reinterpret_cast<const uint4v *>(mine + lp * LSTR + ch * 16);
-            const long long img = gp / ((long long)p.H * p.W);
+            const long long img = fdiv((uint32_t)gp, p.dHW);
             const long long rem = gp - img * (long long)p.H * p.W;
             *reinterpret_cast<uint4v *>(obase + img * p.out_img_stride + rem * p.out_ld + ch * EPC) = u;
         }
     }
 }
 
-hipError_t launch_first(const FirstParams &p, int dtype, hipStream_t s) {
+hipError_t launch_first(const FirstParams &p0, int dtype, hipStream_t s) {
+    FirstParams p = p0;
     const long long g = (p.total + 255) / 256;      // one workgroup per 256 output pixels
-    if (g < 1 || g > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (g < 1 || p.total > 0x7fffffffLL) return hipErrorInvalidValue;   // 32-bit pixel indices (fdiv)
+    p.dW = make_fastdiv((uint32_t)p.W);
+    p.dH = make_fastdiv((uint32_t)p.H);
+    p.dHW = make_fastdiv((uint32_t)p.H * (uint32_t)p.W);
     const dim3 grid((unsigned)g), block(256);
     if (dtype == YOLO_DTYPE_F16) {
         if (p.Cout == 32) hipLaunchKernelGGL((conv_first_kernel<_Float16, 32>), grid, block, 0, s, p);

@@ -43,6 +43,29 @@ struct Buffer {
 };
 
 // ---- device-side parameter blocks -----------------------------------------------------
+// Division by a launch-time constant without the ~40-instruction software divide (Granlund-Montgomery,
+// exact for every 32-bit unsigned n): q = (t + ((n - t) >> sh1)) >> sh2 with t = mulhi(mul, n).
+struct FastDiv {
+    uint32_t mul, sh1, sh2, d;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f{1, 0, 0, d ? d : 1};
+    uint32_t l = 0;
+    while ((1ull << l) < f.d) ++l;
+    f.mul = (uint32_t)((((1ull << l) - f.d) << 32) / f.d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+__host__ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t t = __umulhi(f.mul, n);
+#else
+    const uint32_t t = (uint32_t)(((unsigned long long)f.mul * n) >> 32);
+#endif
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
 struct ConvParams {
     const void *in;            // base of the input BUFFER (view offsets are folded into byte offsets)
     const void *wgt;
@@ -66,7 +89,16 @@ struct ConvParams {
     int stagger;               // conv_dma x2 tiles: initial sleep (x8128 cycles) of the second resident workgroup
     int dbg;                   // experiment flags (YOLO_CONV_DBG): 1 skip steady-state DMA, 2 skip MFMA phase
     int qW, qHW, Mq;           // conv_tap.hip: padded-linear pixel grid, row stride W+1, image stride (H+1)(W+1), total
+    FastDiv dHoWo, dWo, dqHW, dqW, dtiles_n, dtpt;   // set by the launchers (conv_set_divisors); dtpt: K stages per tap
 };
+inline void conv_set_divisors(ConvParams &p, int stages_per_tap) {
+    p.dtpt = make_fastdiv((uint32_t)(stages_per_tap > 0 ? stages_per_tap : 1));
+    p.dHoWo = make_fastdiv((uint32_t)p.HoWo);
+    p.dWo = make_fastdiv((uint32_t)p.Wo);
+    p.dqHW = make_fastdiv((uint32_t)(p.qHW > 0 ? p.qHW : 1));
+    p.dqW = make_fastdiv((uint32_t)(p.qW > 0 ? p.qW : 1));
+    p.dtiles_n = make_fastdiv((uint32_t)(p.n_tiles_n > 0 ? p.n_tiles_n : 1));
+}
 
 struct PrepParams {            // float32 NHWC [B,H,W,C] -> T NHWC [B,H,W,Cpad], zero fill
     const float *in;
@@ -82,7 +114,8 @@ struct FirstParams {           // first layer: 3x3/1 conv on the float32 NHWC3 i
     void *out;                 // T NHWC view
     int H, W, Cout, out_ld, leaky, round_half;
     long long out_img_stride;
-    long long total;           // B*H*W output pixels
+    long long total;           // B*H*W output pixels (< 2^31)
+    FastDiv dW, dH, dHW;       // set by launch_first
 };
 
 struct PoolParams {            // net/layers.py:70-81
