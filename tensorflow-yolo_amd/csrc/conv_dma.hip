@@ -229,8 +229,10 @@ static const DmaCfg kCfgs[] = {
     {64, 512, 2, 1.00f, "64x512,K32,S2,x2", 4},    // 7: narrow early layers (Cout <= 64), bandwidth-bound
     {128, 256, 2, 1.00f, "128x256,tap9,x2", 4},        // 8: conv_tap.hip, 3x3/1 only: input patch loaded once for the 9 taps
     {256, 256, 1, 1.00f, "256x256,tap9", 4},           // 9
+    {128, 192, 2, 1.00f, "128x192,tap9,x2", 4},        // 10: smaller position tiles for small feature maps
+    {128, 128, 2, 1.00f, "128x128,tap9,x2", 4},        // 11
 };
-static const int kNumCfgs = 10;
+static const int kNumCfgs = 12;
 static const int kFirstTapCfg = 8;
 
 // Pick the block tile that minimises rounds x tile time on 256 CUs (tail quantisation matters:
@@ -252,18 +254,22 @@ bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok, int ksize, int
 // within ~10 %, e.g. 13x13x512->1024 at batch 16: 124 us predicted on 256x256 (123 measured, 44
 // workgroups on 256 CUs) vs 71 us on 256x128,K64 (75 measured).  yolo_net_autotune replaces the model by
 // on-device timing when asked.
-struct TileCost { float a_shared, a_alone, f; };   // us per K64 tile (CU shared by two workgroups / alone), fixed us per round
+// Two-per-CU tiles have three regimes: more workgroups than the 512 slots (back-filled rounds, `a_shared`), between
+// 257 and 512 (one round, most CUs shared and in lockstep: `a_mid`), at most 256 (a workgroup has its CU alone).
+struct TileCost { float a_shared, a_mid, a_alone, f; };   // us per K64 tile, fixed us per round
 static const TileCost kCost[] = {
-    {1.14f, 0.82f, 9.0f},       // 0: 4-wave 128x128, two per CU
-    {1.45f, 1.45f, 20.0f},      // 1: 256x256 K64 S2
-    {0.82f, 0.82f, 12.0f},      // 2: 256x128 K64 S3
-    {0.82f, 0.82f, 12.0f},      // 3: 128x256 K64 S3
-    {1.47f, 1.47f, 20.0f},      // 4: 256x256 K32 S4
-    {1.75f, 1.30f, 8.0f},       // 5: 256x128 K32 S3, two per CU
-    {1.75f, 1.30f, 8.0f},       // 6: 128x256 K32 S3, two per CU
-    {0.0f, 0.0f, 0.0f},         // 7: 64x512 (bandwidth-bound narrow layers: chosen by rule)
-    {1.30f, 1.00f, 8.0f},       // 8: 128x256 tap reuse, two per CU
-    {1.09f, 1.09f, 22.0f},      // 9: 256x256 tap reuse
+    {1.14f, 1.14f, 0.82f, 9.0f},        // 0: 4-wave 128x128, two per CU
+    {1.45f, 1.45f, 1.45f, 20.0f},       // 1: 256x256 K64 S2
+    {0.82f, 0.82f, 0.82f, 12.0f},       // 2: 256x128 K64 S3
+    {0.82f, 0.82f, 0.82f, 12.0f},       // 3: 128x256 K64 S3
+    {1.47f, 1.47f, 1.47f, 20.0f},       // 4: 256x256 K32 S4
+    {1.75f, 1.75f, 1.30f, 8.0f},        // 5: 256x128 K32 S3, two per CU
+    {1.75f, 1.75f, 1.30f, 8.0f},        // 6: 128x256 K32 S3, two per CU
+    {0.0f, 0.0f, 0.0f, 0.0f},           // 7: 64x512 (bandwidth-bound narrow layers: chosen by rule)
+    {1.20f, 1.45f, 0.76f, 7.9f},        // 8: 128x256 tap reuse, two per CU   (fitted on the sweep of tools/gpu_tile_sweep.sh:
+    {1.20f, 1.20f, 1.20f, 20.0f},       // 9: 256x256 tap reuse                v3-608-b32, v3-416-b32, v2-416-b16, within ~8 %)
+    {0.94f, 1.32f, 0.68f, 8.5f},        // 10: 128x192 tap reuse, two per CU
+    {0.76f, 0.90f, 0.63f, 6.9f},        // 11: 128x128 tap reuse, two per CU
 };
 
 int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W) {
@@ -283,10 +289,17 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
         const long long blocks = (Meff + k.nb - 1) / k.nb * ((cout + k.na - 1) / k.na);
         const long long slots = 256LL * k.slots_per_cu;
         // one workgroup per CU: whole rounds; two per CU: the dispatcher back-fills, the tail costs ~half a round
-        double rounds;
-        if (k.slots_per_cu == 1) rounds = (double)((blocks + slots - 1) / slots);
-        else rounds = blocks <= slots ? 1.0 : (double)blocks / slots + 0.5;
-        const double a = blocks <= 256 ? kCost[c].a_alone : kCost[c].a_shared;
+        double rounds, a;
+        if (k.slots_per_cu == 1) {
+            rounds = (double)((blocks + slots - 1) / slots);
+            a = kCost[c].a_shared;
+        } else if (blocks > slots) {
+            rounds = (double)blocks / slots + 0.5;
+            a = kCost[c].a_shared;
+        } else {
+            rounds = 1.0;
+            a = blocks <= 256 ? kCost[c].a_alone : kCost[c].a_mid;
+        }
         const double t = rounds * (k64 * a + kCost[c].f * (has_res ? 1.0 : 0.7));
         if (t < best_t) { best_t = t; best = c; }
     }

@@ -66,10 +66,9 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     constexpr int CH = 4 * TM;
     constexpr int A_BYTES = NA * ROWB;
     constexpr int P_BYTES = PRG * 1024;
-    constexpr int TRASH = S * A_BYTES + 2 * P_BYTES;    // 1 KiB that absorbs the DMA slots beyond the patch
     static_assert(WM * WN == NW, "eight waves");
     static_assert(JA >= 1 && JA * 16 * NW == NA, "weight tile must split evenly over the waves");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[S * A_BYTES + 2 * P_BYTES + 1024];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[S * A_BYTES + 2 * P_BYTES];
     unsigned char *const smemP = smem + S * A_BYTES;
 
     const int tid = threadIdx.x;
@@ -98,8 +97,10 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         a_off[j] = (uint32_t)(n0 + ch) * p.wrow_bytes + (uint32_t)(((lane & 3) ^ tap_swz_w(lrow)) << 4);
     }
     // patch row R <-> position q0 - (W+2) + R; row group g = j NW + wave
+    // (the last of a wave's JP row groups may lie beyond the patch: waves >= JP_FULL issue one instruction fewer)
+    constexpr int JP_FULL = PRG - (JP - 1) * NW;    // waves that own JP row groups
+    const bool jp_full = wave < JP_FULL;            // wave-uniform
     uint32_t b_off[JP];
-    int b_dst[JP];
     const uint32_t csw_p = (uint32_t)(((lane & 3) ^ (((lrow >> 2) & 1) << 1)) << 4);
 #pragma unroll
     for (int j = 0; j < JP; ++j) {
@@ -114,7 +115,6 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         ok = ok && x < p.W && y < p.H;
         const long long e = (long long)n * p.in_img_stride + ((long long)y * p.W + x) * p.in_ld + p.in_coff;
         b_off[j] = ok ? (uint32_t)(e * 2) + csw_p : YOLO_INVALID_OFF;
-        b_dst[j] = g < PRG ? g * 1024 : TRASH - S * A_BYTES;    // relative to smemP (wave-uniform)
     }
 
     const int C = p.cin_chunks >> 2;        // 32-channel slices
@@ -122,10 +122,8 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     auto issue_patch = [&](int c, int buf) {
         const uint32_t koff = (uint32_t)c * ROWB;
 #pragma unroll
-        for (int j = 0; j < JP; ++j) {
-            unsigned char *dst = smemP + b_dst[j] + (b_dst[j] < 2 * P_BYTES ? buf * P_BYTES : 0);
-            tap_dma16(rs_in, dst, b_off[j], koff);
-        }
+        for (int j = 0; j < JP; ++j)
+            if (j + 1 < JP || jp_full) tap_dma16(rs_in, smemP + buf * P_BYTES + (j * NW + wave) * 1024, b_off[j], koff);
     };
     auto issue_weights = [&](int tap, int c, int slot) {
         const uint32_t ka = (uint32_t)(tap * p.cin_chunks + 4 * c) * 16;
@@ -173,7 +171,10 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
             // patch; younger than weights(tap) are weights(tap+1) and, at taps 1 and 2, that patch.
             const bool last = !more && tap == 8;
             if (last) tap_wait_vm<0>();
-            else if (more && (tap == 1 || tap == 2)) tap_wait_vm<JA + JP>();
+            else if (more && (tap == 1 || tap == 2)) {
+                if (jp_full) tap_wait_vm<JA + JP>();
+                else tap_wait_vm<JA + JP - 1>();
+            }
             else tap_wait_vm<JA>();
             __builtin_amdgcn_s_barrier();
             {   // weights two taps ahead
@@ -195,10 +196,13 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     conv_epilogue<T, TM, TP, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
 }
 
-// variant 0: 128 couts x 256 positions, two workgroups per CU (W <= 78); variant 1: 256 x 256, one per CU
+// variants: 0 = 128 couts x 256 positions, 1 = 256 x 256 (one workgroup per CU), 2 = 128 x 192, 3 = 128 x 128
+// (smaller position tiles fill the 512 workgroup slots of the chip better on small feature maps)
+static const int kTapNB[] = {256, 256, 192, 128};
+static const int kTapPRG[] = {26, 26, 26, 28};
 bool conv_tap_fits(int variant, int W) {
-    const int prg = variant == 0 ? 26 : 26;
-    return 256 + 2 * W + 4 <= prg * 16;
+    if (variant < 0 || variant > 3) return false;
+    return kTapNB[variant] + 2 * W + 4 <= kTapPRG[variant] * 16;
 }
 
 hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
@@ -208,6 +212,8 @@ hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
     switch (variant) {
     case 0: hipLaunchKernelGGL((conv3x3_tap_kernel<2, 4, 4, 4, 26, 4>), grid, dim3(512), 0, s, p); break;
     case 1: hipLaunchKernelGGL((conv3x3_tap_kernel<2, 4, 8, 4, 26, 2>), grid, dim3(512), 0, s, p); break;
+    case 2: hipLaunchKernelGGL((conv3x3_tap_kernel<2, 4, 4, 3, 26, 4>), grid, dim3(512), 0, s, p); break;
+    case 3: hipLaunchKernelGGL((conv3x3_tap_kernel<2, 4, 4, 2, 28, 4>), grid, dim3(512), 0, s, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
