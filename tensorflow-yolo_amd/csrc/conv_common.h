@@ -40,50 +40,82 @@ __device__ __forceinline__ float4v mma_chunk<float>(const uint4v &a, const uint4
 // index map (identity / nearest-upsample x2 layers.py:115 / block-major reorg layers.py:92-96).
 // PADQ (conv_tap.hip): the pixel index is a position q of the padded-linear grid [n][y <= H][x <= W] (one shared
 // zero row / column between image rows and images); pad positions are computed but never stored.
+template <bool PADQ>
+__device__ __forceinline__ bool conv_decode_pixel(const ConvParams &p, int m, int &n, int &rem, int &oy, int &ox) {
+    bool ok;
+    if (PADQ) {
+        ok = m < p.Mq;
+        const int mm = ok ? m : 0;
+        n = (int)fdiv((uint32_t)mm, p.dqHW);
+        const int r = mm - n * p.qHW;
+        oy = (int)fdiv((uint32_t)r, p.dqW);
+        ox = r - oy * p.qW;
+        ok = ok && ox != p.Wo && oy != p.Ho;
+        rem = oy * p.Wo + ox;
+    } else {
+        ok = m < p.M;
+        const int mm = ok ? m : 0;
+        n = (int)fdiv((uint32_t)mm, p.dHoWo);
+        rem = mm - n * p.HoWo;
+        oy = (int)fdiv((uint32_t)rem, p.dWo);
+        ox = rem - oy * p.Wo;
+    }
+    return ok;
+}
+
 template <typename T, int TM, int TP, bool PADQ = false>
-__device__ __forceinline__ void conv_epilogue(const ConvParams &p, const float4v (&acc)[TM][TP], int cbase, int m_wave, int fr) {
+__device__ __forceinline__ void conv_epilogue(const ConvParams &p, float4v (&acc)[TM][TP], int cbase, int m_wave, int fr) {
     constexpr int CH = 4 * TM;
     constexpr int EPC = 16 / (int)sizeof(T);
     if (cbase >= p.Cout) return;
-    float bias[CH];
-#pragma unroll
-    for (int i = 0; i < CH; ++i) bias[i] = p.bias[cbase + i];      // bias is padded to 128 couts
     const int nvalid = p.Cout - cbase < CH ? p.Cout - cbase : CH;
+    {   // bias + activation in place: the bias registers die before the residual chunks arrive
+        float bias[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) bias[i] = p.bias[cbase + i];      // bias is padded to 128 couts
+#pragma unroll
+        for (int b = 0; b < TP; ++b)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = acc[a][b][j] + bias[4 * a + j];
+                    acc[a][b][j] = p.leaky ? fmaxf(0.1f * x, x) : x;
+                }
+    }
+    // (fp16) every residual chunk of the wave is requested before the first one is used: the epilogue was a chain
+    // of TP dependent load -> store round trips (~1 us each under load, 3.8 us per workgroup in the block trace of
+    // conv_tap.hip) while the accumulators sat idle.  The cheap pixel decode is simply done twice.
+    constexpr bool PRELOAD = sizeof(T) == 2;
+    uint4v rv[PRELOAD ? TP : 1][PRELOAD ? CH / EPC : 1];
+    if (PRELOAD && p.has_res && p.vec_res) {
+#pragma unroll
+        for (int b = 0; b < TP; ++b) {
+            int n, rem, oy, ox;
+            const bool ok = conv_decode_pixel<PADQ>(p, m_wave + b * 16 + fr, n, rem, oy, ox);
+            // pad / tail lanes read the first pixel's residual (always in range) and ignore it
+            const long long ro = ok ? (long long)n * p.res_img_stride + (long long)rem * p.res_ld : 0;
+            const T *rp = reinterpret_cast<const T *>(p.res) + ro + cbase;
+#pragma unroll
+            for (int q = 0; q < CH / EPC; ++q) rv[PRELOAD ? b : 0][PRELOAD ? q : 0] = *reinterpret_cast<const uint4v *>(rp + q * EPC);
+        }
+    }
 
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
-        const int m = m_wave + b * 16 + fr;
         int n, rem, oy, ox;
-        if (PADQ) {
-            if (m >= p.Mq) continue;
-            n = (int)fdiv((uint32_t)m, p.dqHW);
-            const int r = m - n * p.qHW;
-            oy = (int)fdiv((uint32_t)r, p.dqW);
-            ox = r - oy * p.qW;
-            if (ox == p.Wo || oy == p.Ho) continue;
-            rem = oy * p.Wo + ox;
-        } else {
-            if (m >= p.M) continue;
-            n = (int)fdiv((uint32_t)m, p.dHoWo);
-            rem = m - n * p.HoWo;
-            oy = (int)fdiv((uint32_t)rem, p.dWo);
-            ox = rem - oy * p.Wo;
-        }
+        if (!conv_decode_pixel<PADQ>(p, m_wave + b * 16 + fr, n, rem, oy, ox)) continue;
         float v[CH];
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 * a + j] = acc[a][b][j] + bias[4 * a + j];
-        if (p.leaky) {
-#pragma unroll
-            for (int i = 0; i < CH; ++i) v[i] = fmaxf(0.1f * v[i], v[i]);
-        }
+            for (int j = 0; j < 4; ++j) v[4 * a + j] = acc[a][b][j];
         if (p.has_res) {
             const T *rp = reinterpret_cast<const T *>(p.res) + (long long)n * p.res_img_stride + (long long)rem * p.res_ld + cbase;
             if (p.vec_res) {
 #pragma unroll
                 for (int q = 0; q < CH / EPC; ++q) {
-                    const uint4v u = *reinterpret_cast<const uint4v *>(rp + q * EPC);
+                    const uint4v u = PRELOAD ? rv[PRELOAD ? b : 0][PRELOAD ? q : 0] : *reinterpret_cast<const uint4v *>(rp + q * EPC);
                     T t[EPC];
                     __builtin_memcpy(t, &u, 16);
 #pragma unroll

@@ -15,6 +15,8 @@
 // Per K tile: wait(tile kt landed) -> barrier -> issue DMA of tile kt+S-1 into the stage read at
 // kt-1 -> ds_read fragments + MFMAs of tile kt.
 #include "conv_common.h"
+#include <cstdio>
+#include <vector>
 
 namespace yolo {
 
@@ -335,6 +337,30 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
         p.Mq = (int)mq;
         p.n_blocks = (int)qblocks;
         conv_set_divisors(p, p.cin_chunks / k.bkc);
+        // experiment: YOLO_CONV_TRACE=<file> appends, for every tap-reuse launch, a header {blocks, M, Cout, cin_chunks,
+        // H, W, cfg, 0} and 8 uint64 per block (see the kernel); synchronous, for tools/trace_blocks.py only
+        if (const char *tf = getenv("YOLO_CONV_TRACE")) {
+            unsigned long long *dev = nullptr;
+            const size_t bytes = (size_t)p.n_blocks * 64;
+            if (hipMalloc((void **)&dev, bytes) != hipSuccess) return hipErrorOutOfMemory;
+            p.trace = dev;
+            hipError_t e = launch_conv_tap(p, cfg - kFirstTapCfg, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            std::vector<unsigned long long> host((size_t)p.n_blocks * 8);
+            if (e == hipSuccess) e = hipMemcpy(host.data(), dev, bytes, hipMemcpyDeviceToHost);
+            (void)hipFree(dev);
+            if (e == hipSuccess) {
+                if (FILE *fp = fopen(tf, "ab")) {
+                    const unsigned long long hdr[8] = {(unsigned long long)p.n_blocks, (unsigned long long)p.M, (unsigned long long)p.Cout,
+                                                       (unsigned long long)p.cin_chunks, (unsigned long long)p.H, (unsigned long long)p.W,
+                                                       (unsigned long long)cfg, 0ull};
+                    fwrite(hdr, 8, 8, fp);
+                    fwrite(host.data(), 8, host.size(), fp);
+                    fclose(fp);
+                }
+            }
+            return e;
+        }
         return launch_conv_tap(p, cfg - kFirstTapCfg, s);
     }
     const dim3 grid((unsigned)blocks), block(512);

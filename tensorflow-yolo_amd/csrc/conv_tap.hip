@@ -72,6 +72,8 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     unsigned char *const smemP = smem + S * A_BYTES;
 
     const int tid = threadIdx.x;
+    const unsigned long long t_start = p.trace ? wall_clock64() : 0ull;
+    const unsigned long long c_start = p.trace ? (unsigned long long)clock64() : 0ull;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -157,6 +159,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     };
 
     // ---- prologue: patch of slice 0, weights of taps 0 and 1 --------------------------------------
+    const unsigned long long t_setup = p.trace ? wall_clock64() : 0ull;
     issue_patch(0, 0);
     issue_weights(0, 0, 0);
     issue_weights(1, 0, 1);
@@ -180,11 +183,11 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
             {   // weights two taps ahead
                 const int t2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;
                 const int c2 = tap + 2 < 9 ? c : c + 1;
-                if (c2 < C && !(p.dbg & 1)) issue_weights(t2, c2, (tap + 2) % S);
+                if (c2 < C) issue_weights(t2, c2, (tap + 2) % S);
             }
-            if (tap == 0 && more && !(p.dbg & 1)) issue_patch(c + 1, buf ^ 1);
+            if (tap == 0 && more) issue_patch(c + 1, buf ^ 1);
             const int kh = tap / 3, kw = tap - 3 * kh;
-            if (!(p.dbg & 2)) compute(tap % S, buf, kh * p.qW + kw);
+            compute(tap % S, buf, kh * p.qW + kw);
         }
     };
     for (int c = 0; c < C; c += 2) {
@@ -192,8 +195,17 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         if (c + 1 < C) run_slice(c + 1, std::integral_constant<int, 1>());
     }
     (void)KT;
-    if (p.dbg & 4) return;              // experiment flags (YOLO_CONV_DBG): 1 no steady-state DMA, 2 no MFMA phase, 4 no epilogue
+    const unsigned long long t_loop = p.trace ? wall_clock64() : 0ull;
     conv_epilogue<T, TM, TP, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
+    if (p.trace && tid == 0) {          // YOLO_CONV_TRACE: phase timestamps (100 MHz) + placement of wave 0 of every block
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long *r = p.trace + (size_t)blockIdx.x * 8;
+        r[0] = t_start; r[1] = t_setup; r[2] = t_loop; r[3] = wall_clock64();
+        r[4] = __builtin_amdgcn_s_getreg(0xF804);      // HW_ID
+        r[5] = __builtin_amdgcn_s_getreg(0xF814);      // XCC_ID
+        r[6] = (unsigned long long)bid;
+        r[7] = (unsigned long long)clock64() - c_start;     // shader-clock cycles of the block (vs r[3] - r[0] at 100 MHz)
+    }
 }
 
 // variants: 0 = 128 couts x 256 positions, 1 = 256 x 256 (one workgroup per CU), 2 = 128 x 192, 3 = 128 x 128

@@ -89,6 +89,7 @@ struct ConvParams {
     int stagger;               // conv_dma x2 tiles: initial sleep (x8128 cycles) of the second resident workgroup
     int dbg;                   // experiment flags (YOLO_CONV_DBG): 1 skip steady-state DMA, 2 skip MFMA phase
     int qW, qHW, Mq;           // conv_tap.hip: padded-linear pixel grid, row stride W+1, image stride (H+1)(W+1), total
+    unsigned long long *trace; // conv_tap.hip: per-block phase timestamps (YOLO_CONV_TRACE experiment) or null
     FastDiv dHoWo, dWo, dqHW, dqW, dtiles_n, dtpt;   // set by the launchers (conv_set_divisors); dtpt: K stages per tap
 };
 inline void conv_set_divisors(ConvParams &p, int stages_per_tap) {

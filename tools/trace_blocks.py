@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Experiment: per-block phase timeline of the tap-reuse conv (YOLO_CONV_TRACE).  Runs the v3-608 b32 forward once
+with tracing, then prints, for each traced layer shape (last launch of it): phase durations, how many workgroups are
+in which phase over time, and how the two workgroups of a CU overlap."""
+import os, sys, struct
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+path = "/tmp/yolo_conv_trace.bin"
+if len(sys.argv) > 1:
+    path = sys.argv[1]
+else:
+    if os.path.exists(path):
+        os.remove(path)
+    import torch
+    from tensorflow_yolo_amd import YoloV3
+    from tensorflow_yolo_amd.net import synth
+    import bench
+    names = ["c%d" % i for i in range(80)]
+    model = YoloV3()
+    net = YoloV3.create_network(np.reshape(bench.COCO_V3, [-1, 2]), names, False, input_shape=(608, 608, 3))
+    w = synth.darknet_stream(net, seed=0, num_classes=80)
+    model.build(bench.COCO_V3, names, (608, 608, 3), dtype="fp16", max_batch=32, weights=w)
+    eng = model.net.engine
+    x = torch.from_numpy(synth.synthetic_input(32, 608, 608, 3, seed=1)).cuda()
+    for _ in range(2):
+        eng.forward(x)
+    torch.cuda.synchronize()
+    os.environ["YOLO_CONV_TRACE"] = path
+    eng.forward(x)
+    torch.cuda.synchronize()
+    del os.environ["YOLO_CONV_TRACE"]
+raw = np.fromfile(path, dtype=np.uint64)
+pos = 0
+layers = {}
+while pos < len(raw):
+    hdr = raw[pos:pos + 8]; pos += 8
+    nb = int(hdr[0])
+    rec = raw[pos:pos + nb * 8].reshape(nb, 8); pos += nb * 8
+    layers[tuple(int(v) for v in hdr[1:7])] = rec
+for key, rec in layers.items():
+    M, cout, cpt, H, W, cfg = key
+    t = rec[:, :4].astype(np.int64)
+    t0 = t[:, 0].min()
+    t = (t - t0) / 100.0                      # us (100 MHz)
+    hw = rec[:, 4]; xcc = rec[:, 5] & 0xf
+    cu = ((hw >> 8) & 0xf).astype(int); se = ((hw >> 13) & 0x7).astype(int); sh = ((hw >> 12) & 1).astype(int)
+    cuid = (xcc.astype(int) * 8 + se) * 32 + sh * 16 + cu
+    print("== layer %dx%d cin %d -> %d, tile %d: %d blocks on %d CUs, span %.1f us" % (H, W, cpt * 8, cout, cfg, len(rec), len(set(cuid)), t[:, 3].max()))
+    cyc = rec[:, 7].astype(np.float64)
+    print("   shader clock during the blocks: %.0f MHz (median of cycles / wall time)" % np.median(cyc / ((rec[:, 3] - rec[:, 0]).astype(np.float64) / 100.0)))
+    d = np.stack([t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]], 1)
+    for i, nm in enumerate(["setup", "prologue+K loop", "epilogue"]):
+        print("   %-16s mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f us" % (nm, d[:, i].mean(), *np.percentile(d[:, i], [10, 50, 90])))
+    # occupancy over time
+    T = t[:, 3].max()
+    grid = np.linspace(0, T, 41)
+    print("   time(us)  in-setup  in-loop  in-epilogue  (workgroups)")
+    for g in grid[:-1]:
+        a = ((t[:, 0] <= g) & (g < t[:, 1])).sum(); b = ((t[:, 1] <= g) & (g < t[:, 2])).sum(); c = ((t[:, 2] <= g) & (g < t[:, 3])).sum()
+        print("   %7.1f  %8d %8d %8d" % (g, a, b, c))
+    # per-CU: fraction of time with 2, 1, 0 workgroups in the K loop
+    tot = np.zeros(3)
+    for c in set(cuid):
+        idx = np.where(cuid == c)[0]
+        ev = sorted([(t[i, 1], 1) for i in idx] + [(t[i, 2], -1) for i in idx])
+        cur = 0; last = 0.0
+        for tm, dl in ev:
+            tot[min(cur, 2)] += tm - last; last = tm; cur += dl
+        tot[0] += T - last
+    print("   per-CU time with 0 / 1 / 2 workgroups inside the K loop: %.1f%% / %.1f%% / %.1f%%" % tuple(100 * tot / tot.sum()))
