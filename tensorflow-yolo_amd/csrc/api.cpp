@@ -229,6 +229,24 @@ int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, h
             break;
         }
         case K_CONV: {
+            if (k.stem == 2) {      // the previous kernel (first layer) is folded into this launch
+                const Kernel &f = net->kernels[ki - 1];
+                StemParams p;
+                memset(&p, 0, sizeof p);
+                p.in = in_dev;
+                p.w1 = reinterpret_cast<const float *>(net->dev_weights + f.w_off);
+                p.b1 = reinterpret_cast<const float *>(net->dev_weights + f.b_off);
+                p.w2 = net->dev_weights + k.w_off;
+                p.b2 = reinterpret_cast<const float *>(net->dev_weights + k.b_off);
+                p.w2_bytes = (uint32_t)k.w_bytes;
+                p.wrow2 = (uint32_t)k.ktiles * 128;
+                p.out = P.view_ptr(k.out);
+                p.H = f.in.H; p.W = f.in.W; p.Ho = k.out.H; p.Wo = k.out.W;
+                p.out_ld = k.out.ld; p.out_img_stride = k.out.img_stride;
+                p.in_img_stride = (long long)f.in.H * f.in.W * 3;
+                e = launch_stem(p, batch, s);
+                break;
+            }
             ConvParams p;
             int rc = make_conv_params(net, k, P, batch, p);
             if (rc) return rc;
@@ -236,6 +254,7 @@ int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, h
             break;
         }
         case K_FIRST: {
+            if (k.stem == 1) break;     // runs inside the next kernel (stem.hip)
             FirstParams p;
             p.in = in_dev;
             p.wgt = reinterpret_cast<const float *>(net->dev_weights + k.w_off);
@@ -375,6 +394,14 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         out->flops = 2.0 * li.H * li.W * k.cout * k.ksize * k.ksize * k.cin;
         out->bytes = (double)k.in.H * k.in.W * k.cin * net->esize + elems(k.out) * esz(k.out) + (k.has_res ? elems(k.in2) * net->esize : 0.0);
         out->weight_bytes = (double)k.cout * k.ksize * k.ksize * k.cin * net->esize + 4.0 * k.cout;
+        if (k.stem == 2) {
+            const Kernel &f = net->kernels[kernel - 1];
+            out->flops += 2.0 * f.out.H * f.out.W * f.cout * 27;
+            out->bytes = (double)f.in.H * f.in.W * 3 * 4 + elems(k.out) * esz(k.out);
+            out->weight_bytes += 28.0 * f.cout * 4;
+            snprintf(out->name, sizeof out->name, "conv_stem<f16,3-32-64>");
+            return YOLO_OK;
+        }
         int tile = 0;       // which kernel runs at max_batch (bench.py runs at max_batch)
         if (dma_eligible(net, k))
             tile = k.tile >= 0 ? k.tile : choose_dma_cfg(net->opt.max_batch * li.H * li.W, k.cout, k.cpt, k.ksize * k.ksize, k.has_res, true, k.stride, k.in.W);
@@ -391,6 +418,10 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         out->bytes = (double)k.in.H * k.in.W * 3 * 4 + elems(k.out) * esz(k.out);
         out->weight_bytes = 28.0 * k.cout * 4;
         snprintf(out->name, sizeof out->name, "conv_first<%s,%d>", t, k.cout);
+        if (k.stem == 1) {          // no launch of its own: accounted for in the conv_stem kernel that follows
+            out->flops = 0; out->bytes = 0; out->weight_bytes = 0;
+            snprintf(out->name, sizeof out->name, "conv_first<fused into conv_stem>");
+        }
     } else {
         out->out_h = k.out.H; out->out_w = k.out.W; out->cout = k.out.C; out->cin = k.in.C;
         out->bytes = elems(k.in) * (k.in.f32 ? 4.0 : net->esize) + elems(k.out) * esz(k.out) + (k.has_res ? elems(k.in2) * net->esize : 0.0);
@@ -411,7 +442,7 @@ int yolo_net_autotune(yolo_net *net, const float *in_dev, int batch, void *strea
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     for (Kernel &k : net->kernels) {
-        if (k.kind != K_CONV || !dma_eligible(net, k)) continue;
+        if (k.kind != K_CONV || k.stem == 2 || !dma_eligible(net, k)) continue;
         ConvParams p;
         rc = make_conv_params(net, k, P, batch, p);
         if (rc) break;

@@ -384,6 +384,17 @@ struct Planner {
                 k.b_off = roundup_sz(k.w_off + k.w_bytes, 256);
                 woff = roundup_sz(k.b_off + (size_t)cout_pad * 4, 256);
                 flops += 2.0 * L[i].H * L[i].W * d.filters * taps * cin;
+                // Darknet-53 stem: first-layer kernel + this 3x3/2 32->64 conv as one kernel (stem.hip) when nobody else
+                // reads the 32-channel tensor (keep_all needs it in memory) and the output takes 16-byte stores
+                if (i == 2 && first_direct && !net->kernels.empty() && net->kernels.back().kind == K_FIRST && s == 1 && sole(1, 2) &&
+                    !net->opt.keep_all && net->opt.dtype == YOLO_DTYPE_F16 && d.ksize == 3 && d.stride == 2 && d.filters == 64 &&
+                    L[1].d.filters == 32 && d.leaky && L[1].d.leaky && f.kind == 0 && !has_head[i] && L[1].H % 2 == 0 && L[1].W % 2 == 0 &&
+                    k.out.ld % epc == 0 && (k.out.base + k.out.coff) % epc == 0 && k.out.img_stride % epc == 0 && !k.out.f32 &&
+                    !getenv("YOLO_NO_STEM")) {
+                    net->kernels.back().stem = 1;
+                    k.stem = 2;
+                    k.note += " fused with the first layer (stem.hip): the 32-channel tensor stays in LDS";
+                }
                 net->kernels.push_back(k);
                 L[key].view = k.out; L[key].materialised = true;
                 if (key != i) { L[i].materialised = false; }

@@ -1,0 +1,242 @@
+// Darknet-53 stem, fused (fp16 nets): conv 3x3/1 3->32 + BN + leaky on the caller's float32 image, then conv 3x3/2
+// 32->64 + BN + leaky (net/v3.py: the first two `conv2d_bn_act` layers; net/layers.py:17-66) in ONE kernel.
+//
+// Why: unfused, the 32-channel full-resolution tensor (757 MB at 608x608, batch 32) is written by the first kernel
+// and read back by the second -- 1.5 GB of the 1.9 GB the two layers move; both ran at ~55 % of the HBM roofline
+// (0.34 + 0.38 ms of a 6.2 ms step).  Fused, the tensor only ever exists in LDS: the pair reads 142 MB and writes 378 MB.
+//
+// Persistent workgroups (8 waves, two per CU) keep the layer-2 weights (9 taps x 64 couts x 64 B, swizzled rows) in
+// LDS and walk tiles of 8 x 16 layer-2 outputs x all 64 couts; per tile:
+//   phase 0  the 19 x 35 x 3 float32 input patch, fetched into registers one tile ahead, -> fp16 in LDS (zero
+//            outside the image = layer 1's padding);
+//   phase 1  layer 1 on MFMA for the 17 x 33 positions layer 2 needs: K = 27 (kh, kw, c) padded to one 32-deep
+//            k-step, B fragments gathered from the patch, bias + leaky, ZERO outside the image (= layer 2's
+//            padding), fp16, written as 64-byte rows of an LDS patch whose columns are de-interleaved by parity, so
+//            that the stride-2 taps of 16 consecutive outputs read 16 consecutive rows;
+//   phase 2  layer 2: 9 taps x one k-step, A = weight tile of the tap, B = patch rows (shift-invariant swizzle of
+//            conv_tap.hip), bias + leaky, 32-byte NHWC stores (a lane owns 16 contiguous couts).
+#include "conv_common.h"
+
+namespace yolo {
+
+namespace {
+
+typedef __attribute__((address_space(3))) void stem_lds_void;
+
+__device__ __forceinline__ void stem_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char *lds_dst, uint32_t voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (stem_lds_void *)lds_dst, 16, voff, 0, 0, 0);
+#else
+    (void)rsrc; (void)lds_dst; (void)voff;
+#endif
+}
+
+__device__ __forceinline__ int stem_swz_w(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }   // weight rows: {0,2,3,1}[(r>>2)&3]
+__device__ __forceinline__ int stem_swz_p(int r) { return ((r >> 2) & 1) << 1; }                  // patch rows: any row shift
+
+constexpr int TY = 8, TX = 16;              // layer-2 outputs per workgroup
+constexpr int P1Y = 2 * TY + 1;             // 17 layer-1 rows
+constexpr int P1X = 2 * TX + 1;             // 33 layer-1 columns
+constexpr int NPOS = P1Y * P1X;             // 561 layer-1 positions
+constexpr int NGRP = (NPOS + 15) / 16;      // 36 groups of 16 positions
+constexpr int INY = P1Y + 2, INX = P1X + 2; // 19 x 35 input pixels
+constexpr int IN_LD = 112;                  // halfs per input patch row (35 * 3 = 105, padded)
+constexpr int EVEN_COLS = (P1X + 1) / 2;    // 17 even columns come first in a patch row block
+constexpr int W2_BYTES = 9 * 64 * 64;
+constexpr int P_BYTES = NGRP * 16 * 64;
+constexpr int IN_BYTES = INY * IN_LD * 2;
+
+}  // namespace
+
+__global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
+    typedef _Float16 T;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[W2_BYTES + P_BYTES + IN_BYTES];
+    unsigned char *const sW = smem;
+    unsigned char *const sP = smem + W2_BYTES;
+    T *const sIn = reinterpret_cast<T *>(smem + W2_BYTES + P_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // ---- once per (persistent) workgroup -----------------------------------------------------------
+    // layer-2 weights -> LDS, [tap][64 rows][64 B]; row r of a tap holds cout 16*((r>>2)&3) + 4*(r>>4) + (r&3)
+    {
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w2), 0, p.w2_bytes, 0x00020000);
+        const int lrow = lane >> 2;
+        for (int i = wave; i < 36; i += 8) {
+            const int tap = i >> 2, rg = i & 3;
+            const int r = rg * 16 + lrow;
+            const int co = 16 * ((r >> 2) & 3) + 4 * (r >> 4) + (r & 3);
+            const uint32_t off = (uint32_t)co * p.wrow2 + (uint32_t)tap * 64 + (uint32_t)(((lane & 3) ^ stem_swz_w(lrow)) << 4);
+            stem_dma16(rs_w, sW + i * 1024, off);
+        }
+    }
+    // layer-1 weights as MFMA A fragments: tile t, row rho = fr holds channel 8*(rho>>2) + 4t + (rho&3); k = 8 fq + j
+    uint4v a1[2];
+    float bias1[8], bias2[16];
+    {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ch = 8 * (fr >> 2) + 4 * t + (fr & 3);
+            T h[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * fq + j;
+                const float w = p.w1[(k < 27 ? k : 26) * 32 + ch];      // unconditional load, then select
+                h[j] = k < 27 ? (T)w : (T)0.f;
+            }
+            __builtin_memcpy(&a1[t], h, 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bias1[i] = p.b1[8 * fq + i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bias2[i] = p.b2[16 * fq + i];
+    }
+    // per-lane K decode of the B fragment: k = 8 fq + j -> offset kh * IN_LD + (kw * 3 + c) inside the input patch
+    int koff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * fq + j;
+        const int kh = k / 9;
+        koff[j] = k < 27 ? kh * IN_LD + (k - 9 * kh) : 0;
+    }
+    const int a_frag = fr * 64 + (((fq ^ stem_swz_w(fr)) & 3) << 4);
+
+    // input patch of a tile: thread -> NIN elements (row, col) of the 19 x 105 float block, fetched into registers
+    // one tile ahead (the HBM latency hides behind the previous tile's two MFMA phases)
+    constexpr int NIN = (INY * INX * 3 + 511) / 512;
+    float in_r[NIN];
+    auto tile_origin = [&](int tile, int &n, int &oy0, int &ox0) {
+        const uint32_t tyx = fdiv((uint32_t)tile, p.dtx);
+        const int tx = (int)((uint32_t)tile - tyx * (uint32_t)p.tiles_x);
+        n = (int)fdiv(tyx, p.dty);
+        const int ty = (int)(tyx - (uint32_t)n * (uint32_t)p.tiles_y);
+        oy0 = ty * TY; ox0 = tx * TX;
+    };
+    auto fetch_input = [&](int tile) {
+        int n, oy0, ox0;
+        tile_origin(tile, n, oy0, ox0);
+        const float *img = p.in + (long long)n * p.in_img_stride;
+        const int gy0 = 2 * oy0 - 2, gx3_0 = (2 * ox0 - 2) * 3;
+#pragma unroll
+        for (int it = 0; it < NIN; ++it) {
+            const int idx = it * 512 + tid;
+            const int row = idx / (INX * 3), col = idx - row * (INX * 3);
+            const int gy = gy0 + row, gx3 = gx3_0 + col;
+            const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx3 < (unsigned)(3 * p.W);
+            const float v = img[ok ? ((long long)gy * p.W) * 3 + gx3 : 0];      // always-valid address, then select
+            in_r[it] = ok ? v : 0.f;
+        }
+    };
+
+    int tile = blockIdx.x;
+    fetch_input(tile);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // weights landed (once), first input patch in registers
+    for (; tile < p.n_tiles; tile += gridDim.x) {
+        int n, oy0, ox0;
+        tile_origin(tile, n, oy0, ox0);
+        const int y1_0 = 2 * oy0 - 1, x1_0 = 2 * ox0 - 1;      // layer-1 position of patch element (0, 0)
+        // float32 -> fp16 (same operand rounding as the unfused first-layer kernel)
+#pragma unroll
+        for (int it = 0; it < NIN; ++it) {
+            const int idx = it * 512 + tid;
+            const int row = idx / (INX * 3), col = idx - row * (INX * 3);
+            if (idx < INY * INX * 3) sIn[row * IN_LD + col] = (T)in_r[it];
+        }
+        __syncthreads();    // input patch visible; every wave is past phase 2 of the previous tile (patch P is free)
+        if (tile + (int)gridDim.x < p.n_tiles) fetch_input(tile + gridDim.x);
+
+        // ---- phase 1: layer 1 for the 17 x 33 positions --------------------------------------------
+        for (int g = wave; g < NGRP; g += 8) {
+            const int pp = g * 16 + fr;
+            const bool live = pp < NPOS;
+            const int pc = live ? pp : NPOS - 1;
+            const int py = pc / P1X, px = pc - py * P1X;
+            const T *src = sIn + py * IN_LD + px * 3;
+            T h[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const T v = src[koff[j]];
+                h[j] = (8 * fq + j < 27) ? v : (T)0.f;
+            }
+            uint4v b;
+            __builtin_memcpy(&b, h, 16);
+            float4v d0 = mma_chunk<T>(a1[0], b, float4v{0.f, 0.f, 0.f, 0.f});
+            float4v d1 = mma_chunk<T>(a1[1], b, float4v{0.f, 0.f, 0.f, 0.f});
+            // lane: channels 8 fq + {0..3} (d0) and 8 fq + {4..7} (d1) of position fr
+            const int gy = y1_0 + py, gx = x1_0 + px;
+            const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            T o[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v0 = d0[j] + bias1[j], v1 = d1[j] + bias1[4 + j];
+                v0 = fmaxf(0.1f * v0, v0);
+                v1 = fmaxf(0.1f * v1, v1);
+                o[j] = (T)(inside ? v0 : 0.f);
+                o[4 + j] = (T)(inside ? v1 : 0.f);
+            }
+            uint4v u;
+            __builtin_memcpy(&u, o, 16);
+            const int rowP = py * P1X + ((px & 1) ? EVEN_COLS + (px >> 1) : (px >> 1));
+            if (live) *reinterpret_cast<uint4v *>(sP + rowP * 64 + ((fq ^ stem_swz_p(rowP)) << 4)) = u;
+        }
+        __syncthreads();    // patch P complete; the input patch may be overwritten
+
+        // ---- phase 2: layer 2, wave = output row oy0 + wave, 16 pixels x 64 couts ------------------
+        uint4v fb[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {     // all nine pixel fragments first: their latency overlaps
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            const int rowP = (2 * wave + kh) * P1X + (kw & 1) * EVEN_COLS + fr + (kw >> 1);
+            fb[tap] = *reinterpret_cast<const uint4v *>(sP + rowP * 64 + ((fq ^ stem_swz_p(rowP)) << 4));
+        }
+        float4v acc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            uint4v fa[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const uint4v *>(sW + tap * 4096 + a * 1024 + a_frag);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = mma_chunk<T>(fa[a], fb[tap], acc[a]);
+        }
+        const int oy = oy0 + wave, ox = ox0 + fr;
+        if (oy < p.Ho && ox < p.Wo) {
+            T o[16];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc[a][j] + bias2[4 * a + j];
+                    o[4 * a + j] = (T)fmaxf(0.1f * v, v);
+                }
+            T *op = reinterpret_cast<T *>(p.out) + (long long)n * p.out_img_stride + ((long long)oy * p.Wo + ox) * p.out_ld + fq * 16;
+            uint4v u0, u1;
+            __builtin_memcpy(&u0, o, 16);
+            __builtin_memcpy(&u1, o + 8, 16);
+            *reinterpret_cast<uint4v *>(op) = u0;
+            *reinterpret_cast<uint4v *>(op + 8) = u1;
+        }
+    }
+}
+
+hipError_t launch_stem(const StemParams &p0, int batch, hipStream_t s) {
+    StemParams p = p0;
+    if ((p.H & 1) || (p.W & 1) || p.Ho != p.H / 2 || p.Wo != p.W / 2) return hipErrorInvalidValue;
+    p.tiles_x = (p.Wo + TX - 1) / TX;
+    p.tiles_y = (p.Ho + TY - 1) / TY;
+    p.dtx = make_fastdiv((uint32_t)p.tiles_x);
+    p.dty = make_fastdiv((uint32_t)p.tiles_y);
+    const long long tiles = (long long)batch * p.tiles_x * p.tiles_y;
+    if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    p.n_tiles = (int)tiles;
+    // persistent workgroups: two per CU (78 KB of LDS each), every one walks tiles blockIdx, blockIdx + grid, ...
+    const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);
+    hipLaunchKernelGGL(stem_v3_kernel, dim3(grid), dim3(512), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace yolo

@@ -119,6 +119,20 @@ struct FirstParams {           // first layer: 3x3/1 conv on the float32 NHWC3 i
     FastDiv dW, dH, dHW;       // set by launch_first
 };
 
+struct StemParams {            // stem.hip: fused conv 3x3/1 3->32 + conv 3x3/2 32->64 (both BN + leaky), fp16 nets
+    const float *in;           // [B,H,W,3] float32 (the caller's tensor)
+    const float *w1;           // first layer [27][32] float32 (K_FIRST packing)
+    const float *b1;           // [32]
+    const void *w2;            // second layer, K_CONV packing: [Cout_pad][wrow2 bytes] fp16, K = (kh, kw, 32 cin)
+    const float *b2;           // [Cout_pad]
+    void *out;                 // fp16 NHWC view [B,H/2,W/2,64]
+    uint32_t w2_bytes, wrow2;
+    int H, W, Ho, Wo, out_ld;
+    long long in_img_stride, out_img_stride;
+    int tiles_x, tiles_y, n_tiles;   // set by launch_stem
+    FastDiv dtx, dty;
+};
+
 struct PoolParams {            // net/layers.py:70-81
     const void *in;
     void *out;
@@ -187,6 +201,7 @@ int dma_num_cfgs();
 int dma_cfg_na(int cfg);
 hipError_t launch_prep(const PrepParams &p, int dtype, hipStream_t s);
 hipError_t launch_first(const FirstParams &p, int dtype, hipStream_t s);
+hipError_t launch_stem(const StemParams &p, int batch, hipStream_t s);     // stem.hip
 hipError_t launch_pool(const PoolParams &p, int dtype, hipStream_t s);
 hipError_t launch_eltwise(const EltParams &p, int dtype, hipStream_t s);
 hipError_t launch_decode(const DecodeParams &p, int batch, hipStream_t s);
@@ -203,6 +218,7 @@ struct Kernel {
     int ksize = 0, stride = 0, cout = 0, cin = 0, cin_s = 0, leaky = 0, outmode = 0, has_res = 0;
     int cfg = 0, perchunk = 0, cpt = 0, ktiles = 0;
     int tile = -1;             // conv_dma tile id chosen by yolo_net_autotune (-1: heuristic)
+    int stem = 0;              // 1: first-layer kernel fused away into the next conv; 2: this conv runs as stem.hip with it
     size_t w_off = 0, b_off = 0, w_bytes = 0;   // inside the device weight blob
     size_t w_src = 0;                           // first float of this conv in the Darknet stream
     int batch_norm = 0;

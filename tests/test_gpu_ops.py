@@ -195,6 +195,27 @@ def test_errors_are_reported():
         eng.load_weights(np.zeros(5, np.float32))
 
 
+@pytest.mark.parametrize("shape", [(3, 40, 56), (2, 64, 64), (1, 18, 34), (2, 21, 30)])
+def test_fused_stem(shape):
+    """Darknet-53 stem (stem.hip): first 3x3/1 3->32 conv and the 3x3/2 32->64 conv behind it as one kernel; partial
+    tiles in both directions, several images, image borders (zero padding of BOTH convs); an odd height keeps the
+    two-kernel path"""
+    B, H, W = shape
+    g = new_graph(H, W, 3)
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 3, 2))
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 1, 1))
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 3, 1))
+    g.append(PL.shortcut(g[-1].out, g[-3].out))
+    g.append(PL.max_pool2d(g[-1].out, 2, stride=1))
+    x = synth.synthetic_input(B, H, W, 3, seed=31)
+    eng = check_graph(g, x, "fp16", seed=6)
+    names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
+    assert ("conv_stem" in names) == (H % 2 == 0 and W % 2 == 0), names
+    eng32 = check_graph(g, x, "fp32", seed=6)
+    assert "conv_stem" not in " ".join(ki.name.decode() for ki in eng32.kernel_infos())
+
+
 @pytest.mark.parametrize("tile", [8, 9, 10, 11])
 def test_tap_reuse_tile_configs(tile, monkeypatch):
     """tap-reuse tiles of conv_tap.hip (3x3/1 only: patch of 1, 2, 4 and 6 channel slices, image borders inside a
