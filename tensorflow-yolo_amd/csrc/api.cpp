@@ -573,7 +573,7 @@ int yolo_nms_host(const double *xywh, const float *prob, const int32_t *class_id
             hipMemcpy(keep_idx, d_i, sizeof(int) * (size_t)kept, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(YOLO_ERR_HIP, "yolo_nms_host: D2H copy failed"); break; }
         *n_keep = kept;
     } while (0);
-    hipFree(dev);
+    (void)hipFree(dev);
     return rc;
 }
 

@@ -36,7 +36,6 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     constexpr int LB = NB / 32;
     constexpr int CH = 4 * TM;              // contiguous channels a lane owns per pixel
     constexpr int ES = (int)sizeof(T);
-    constexpr int EPC = 16 / ES;
     constexpr int TILE_BYTES = (NA + NB) * 128;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
 

@@ -68,7 +68,6 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
     constexpr bool A_ALL = JA_TOT % 8 == 0; // every wave issues the same number of weight instructions
     constexpr int NL = JA + JB;             // DMA instructions per stage of a wave that carries weights
     constexpr int KS = BKC / 4;             // 32-deep MFMA k-steps per stage
-    constexpr int SUB = 8 / BKC;            // stages per 64-half K tile of the host-side plan
     constexpr int CH = 4 * TM;
     constexpr int TILE_BYTES = (NA + NB) * ROWB;
     static_assert(JB >= 1 && (A_ALL || JA_TOT < 8), "unsupported tile for the DMA mapping");
@@ -85,15 +84,6 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
     const int nt = bid - mt * p.n_tiles_n;
     const int n0 = nt * NA;
     const int m0 = mt * NB;
-
-    // Two workgroups share a CU (OCC 4).  Dispatched together they would run in lockstep -- both in
-    // the MFMA loop, then both in the memory-bound epilogue.  The second resident workgroup of each
-    // CU (observed placement: blocks 256..511 of the first wave; speed only, never correctness)
-    // sleeps for about half a workgroup period once, so from then on one computes while the other
-    // loads residuals / stores outputs.
-    if (OCC == 4 && p.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wgt), 0, p.wgt_bytes, 0x00020000);
@@ -318,11 +308,6 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
     ConvParams p = p0;
     const DmaCfg &k = kCfgs[cfg];
     { const char *d = getenv("YOLO_CONV_DBG"); p.dbg = d ? atoi(d) : 0; }
-    {   // stagger = f x (estimated MFMA-bound K-loop time of one workgroup sharing the CU) in 8128-cycle sleeps
-        const char *d = getenv("YOLO_CONV_STAGGER");
-        const double f = d ? atof(d) : 0.0;
-        p.stagger = k.slots_per_cu == 2 ? (int)(f * p.ktiles * 2 * 1365.0 / 8128.0 + 0.5) : 0;
-    }
     p.n_tiles_n = (p.Cout + k.na - 1) / k.na;
     const long long blocks = ((long long)p.M + k.nb - 1) / k.nb * p.n_tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;

@@ -86,7 +86,6 @@ struct ConvParams {
     uint32_t wrow_bytes;
     int leaky, has_res, outmode, out_f32, vec_out, vec_res;
     int n_tiles_n, n_blocks;
-    int stagger;               // conv_dma x2 tiles: initial sleep (x8128 cycles) of the second resident workgroup
     int dbg;                   // experiment flags (YOLO_CONV_DBG): 1 skip steady-state DMA, 2 skip MFMA phase
     int qW, qHW, Mq;           // conv_tap.hip: padded-linear pixel grid, row stride W+1, image stride (H+1)(W+1), total
     unsigned long long *trace; // conv_tap.hip: per-block phase timestamps (YOLO_CONV_TRACE experiment) or null
