@@ -40,10 +40,22 @@ __device__ __forceinline__ float4v mma_chunk<float>(const uint4v &a, const uint4
 // index map (identity / nearest-upsample x2 layers.py:115 / block-major reorg layers.py:92-96).
 // PADQ (conv_tap.hip): the pixel index is a position q of the padded-linear grid [n][y <= H][x <= W] (one shared
 // zero row / column between image rows and images); pad positions are computed but never stored.
-template <bool PADQ>
+// PADQ 0: dense pixel index; 1: padded-linear position (conv_tap.hip MODE 1); 2: position inside 2-D tiles of
+// (256 / 16) x 16 pixels (conv_tap.hip MODE 2: qW = tiles per tile row, qHW = tiles per image)
+template <int PADQ>
 __device__ __forceinline__ bool conv_decode_pixel(const ConvParams &p, int m, int &n, int &rem, int &oy, int &ox) {
     bool ok;
-    if (PADQ) {
+    if (PADQ == 2) {
+        const int tile = m >> 8, l = m & 255;
+        n = (int)fdiv((uint32_t)tile, p.dqHW);
+        const int r = tile - n * p.qHW;
+        const int ty = (int)fdiv((uint32_t)r, p.dqW);
+        oy = ty * 16 + (l >> 4);
+        ox = (r - ty * p.qW) * 16 + (l & 15);
+        ok = m < p.Mq && oy < p.Ho && ox < p.Wo;
+        if (!ok) { n = 0; oy = 0; ox = 0; }
+        rem = oy * p.Wo + ox;
+    } else if (PADQ == 1) {
         ok = m < p.Mq;
         const int mm = ok ? m : 0;
         n = (int)fdiv((uint32_t)mm, p.dqHW);
@@ -63,7 +75,7 @@ __device__ __forceinline__ bool conv_decode_pixel(const ConvParams &p, int m, in
     return ok;
 }
 
-template <typename T, int TM, int TP, bool PADQ = false>
+template <typename T, int TM, int TP, int PADQ = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, float4v (&acc)[TM][TP], int cbase, int m_wave, int fr) {
     constexpr int CH = 4 * TM;
     constexpr int EPC = 16 / (int)sizeof(T);

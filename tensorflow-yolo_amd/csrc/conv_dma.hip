@@ -223,8 +223,10 @@ static const DmaCfg kCfgs[] = {
     {256, 256, 1, 1.00f, "256x256,tap9", 4},           // 9
     {128, 192, 2, 1.00f, "128x192,tap9,x2", 4},        // 10: smaller position tiles for small feature maps
     {128, 128, 2, 1.00f, "128x128,tap9,x2", 4},        // 11
+    {128, 256, 2, 1.00f, "128x256,tap9,2d,x2", 4},     // 12: 2-D 16x16 tiles for maps wider than 78
+    {64, 256, 2, 1.00f, "64x256,tap9,2d,x2", 4},       // 13: ... and Cout <= 64
 };
-static const int kNumCfgs = 12;
+static const int kNumCfgs = 14;
 static const int kFirstTapCfg = 8;
 
 // Pick the block tile that minimises rounds x tile time on 256 CUs (tail quantisation matters:
@@ -235,7 +237,7 @@ bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok, int ksize, int
     const DmaCfg &k = kCfgs[cfg];
     if (cin_chunks % k.bkc) return false;
     if (cfg >= kFirstTapCfg && (ksize != 3 || stride != 1 || !conv_tap_fits(cfg - kFirstTapCfg, W))) return false;
-    if (k.na == 64) return cout <= 64;
+    if (k.na == 64) return cout <= 64 && (cfg < kFirstTapCfg || cout > 32);
     return k.na <= (cout + 127) / 128 * 128 && cout > 64;
 }
 
@@ -262,6 +264,8 @@ static const TileCost kCost[] = {
     {1.20f, 1.20f, 1.20f, 20.0f},       // 9: 256x256 tap reuse                v3-608-b32, v3-416-b32, v2-416-b16, within ~8 %)
     {0.94f, 1.32f, 0.68f, 8.5f},        // 10: 128x192 tap reuse, two per CU
     {0.76f, 0.90f, 0.63f, 6.9f},        // 11: 128x128 tap reuse, two per CU
+    {0.90f, 1.10f, 0.60f, 17.0f},       // 12: 128x256 tap reuse, 2-D tiles (152x152 64->128: 175 us, 76x76: 117, 38x38: 138)
+    {1.00f, 1.00f, 0.60f, 5.8f},        // 13: 64x256 tap reuse, 2-D tiles (chosen by rule below)
 };
 
 int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W) {
@@ -269,15 +273,22 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
     const char *force = getenv("YOLO_CONV_TILE");
     if (force && *force && dma_cfg_valid(atoi(force), cout, cin_chunks, v1_ok, ksize, stride, W)) return atoi(force);
     const int fallback = v1_ok ? 0 : -1;
-    if (cout <= 64) return dma_cfg_valid(7, cout, cin_chunks, v1_ok, ksize, stride, W) && M >= 8192 ? 7 : fallback;
+    if (cout <= 64) {   // narrow, bandwidth-bound layers: 3x3/1 with tap reuse (304x304 32->64: 239 us vs 273 on the 64x512 tile)
+        if (M >= 8192 && dma_cfg_valid(13, cout, cin_chunks, v1_ok, ksize, stride, W)) return 13;
+        return dma_cfg_valid(7, cout, cin_chunks, v1_ok, ksize, stride, W) && M >= 8192 ? 7 : fallback;
+    }
     const double k64 = taps * cin_chunks / 8.0;         // 64-deep K tiles
     int best = fallback;
     double best_t = 1e300;
     for (int c = 0; c < kNumCfgs; ++c) {
-        if (c == 7 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
+        if (c == 7 || c == 13 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
         const DmaCfg &k = kCfgs[c];
         // tap-reuse tiles walk the padded position grid: (H+1)(W+1) positions per image (square maps assumed here)
-        const long long Meff = c >= kFirstTapCfg ? (long long)M * (W + 1) * (W + 1) / ((long long)W * W) : M;
+        long long Meff = M;
+        if (c >= kFirstTapCfg) {
+            if (conv_tap_is2d(c - kFirstTapCfg)) { const long long t = (W + 15) / 16; Meff = (long long)M * t * t * 256 / ((long long)W * W); }
+            else Meff = (long long)M * (W + 1) * (W + 1) / ((long long)W * W);
+        }
         const long long blocks = (Meff + k.nb - 1) / k.nb * ((cout + k.na - 1) / k.na);
         const long long slots = 256LL * k.slots_per_cu;
         // one workgroup per CU: whole rounds; two per CU: the dispatcher back-fills, the tail costs ~half a round
@@ -314,9 +325,16 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
     p.n_blocks = (int)blocks;
     conv_set_divisors(p, p.cin_chunks / k.bkc);
     if (cfg >= kFirstTapCfg) {      // padded-linear position grid: one shared pad column per row, one pad row per image
-        p.qW = p.W + 1;
-        p.qHW = (p.H + 1) * (p.W + 1);
-        const long long mq = (long long)(p.M / p.HoWo) * p.qHW;
+        long long mq;
+        if (conv_tap_is2d(cfg - kFirstTapCfg)) {     // 16 x 16 tiles: qW = tiles per tile row, qHW = tiles per image
+            p.qW = (p.W + 15) / 16;
+            p.qHW = p.qW * ((p.H + 15) / 16);
+            mq = (long long)(p.M / p.HoWo) * p.qHW * 256;
+        } else {
+            p.qW = p.W + 1;
+            p.qHW = (p.H + 1) * (p.W + 1);
+            mq = (long long)(p.M / p.HoWo) * p.qHW;
+        }
         const long long qblocks = (mq + k.nb - 1) / k.nb * p.n_tiles_n;
         if (qblocks <= 0 || qblocks > 0x7fffffffLL) return hipErrorInvalidValue;
         p.Mq = (int)mq;

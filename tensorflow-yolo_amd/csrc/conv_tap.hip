@@ -53,7 +53,11 @@ __device__ __forceinline__ int tap_swz_w(int r) { return (0x78 >> (2 * ((r >> 2)
 }  // namespace
 
 // 8 waves = WM x WN; a wave owns TM*16 couts x TP*16 positions; PRG = 16-row groups of one patch buffer.
-template <int WM, int WN, int TM, int TP, int PRG, int OCC>
+// MODE 1: padded-linear positions (above).  MODE 2: 2-D tiles for wide maps, where 2W+4 halo positions would not fit:
+// a block owns TH x 16 output pixels (TH = NB / 16, fragment = one tile row), the patch is (TH + 2) rows of PW = 24
+// slots (18 used: PW a multiple of 8 keeps the swizzle phase of every fragment row equal, so fragment offsets stay
+// immediates), tap shift kh * 24 + kw; pixels of partial tiles outside the image are computed and dropped.
+template <int WM, int WN, int TM, int TP, int PRG, int OCC, int MODE = 1>
 __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams p) {
     typedef _Float16 T;
     constexpr int NW = 8;
@@ -61,13 +65,17 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     constexpr int ROWB = 64;
     constexpr int NA = WM * TM * 16;
     constexpr int NB = WN * TP * 16;
-    constexpr int JA = NA / (16 * NW);      // weight DMA wave-instructions per wave per tap
+    constexpr int JA_TOT = NA / 16;         // weight DMA wave-instructions per tap
+    constexpr int JA = (JA_TOT + NW - 1) / NW;      // per wave (a 64-cout tile has 4: waves 4..7 carry none)
+    constexpr int PW = 24;                  // MODE 2: patch row pitch in positions
+    constexpr int FROW = MODE == 2 ? PW : 16;       // patch rows between consecutive fragments of a wave
     constexpr int JP = (PRG + NW - 1) / NW; // patch DMA wave-instructions per wave per slice
     constexpr int CH = 4 * TM;
     constexpr int A_BYTES = NA * ROWB;
     constexpr int P_BYTES = PRG * 1024;
     static_assert(WM * WN == NW, "eight waves");
-    static_assert(JA >= 1 && JA * 16 * NW == NA, "weight tile must split evenly over the waves");
+    static_assert(JA_TOT % NW == 0 || JA_TOT < NW, "weight tile must split evenly over the waves (or be smaller than them)");
+    static_assert(MODE == 1 || PRG * 16 >= (NB / 16 + 2) * PW, "patch buffer too small for the 2-D tile");
     __shared__ __attribute__((aligned(16))) unsigned char smem[S * A_BYTES + 2 * P_BYTES];
     unsigned char *const smemP = smem + S * A_BYTES;
 
@@ -83,6 +91,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     const int nt = bid - mt * p.n_tiles_n;
     const int n0 = nt * NA;
     const int q0 = mt * NB;
+    const bool has_a = JA_TOT % NW == 0 || wave < JA_TOT;   // wave-uniform
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wgt), 0, p.wgt_bytes, 0x00020000);
@@ -104,17 +113,34 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     const bool jp_full = wave < JP_FULL;            // wave-uniform
     uint32_t b_off[JP];
     const uint32_t csw_p = (uint32_t)(((lane & 3) ^ (((lrow >> 2) & 1) << 1)) << 4);
+    int t2_n = 0, t2_y0 = 0, t2_x0 = 0;     // MODE 2: image and first output pixel of this block's tile
+    if (MODE == 2) {
+        t2_n = (int)fdiv((uint32_t)mt, p.dqHW);             // qHW = tiles per image, qW = tiles per tile row
+        const int r = mt - t2_n * p.qHW;
+        const int ty = (int)fdiv((uint32_t)r, p.dqW);
+        t2_y0 = ty * (NB / 16);
+        t2_x0 = (r - ty * p.qW) * 16;
+    }
 #pragma unroll
     for (int j = 0; j < JP; ++j) {
         const int g = j * NW + wave;
-        const int q = q0 - (p.qW + 1) + g * 16 + lrow;
-        bool ok = g < PRG && q >= 0 && q < p.Mq;
-        const int qq = ok ? q : 0;
-        const int n = (int)fdiv((uint32_t)qq, p.dqHW);
-        const int r = qq - n * p.qHW;
-        const int y = (int)fdiv((uint32_t)r, p.dqW);
-        const int x = r - y * p.qW;
-        ok = ok && x < p.W && y < p.H;
+        bool ok;
+        int n, y, x;
+        if (MODE == 2) {
+            const int R = g * 16 + lrow;
+            const int pr = R / PW, pc = R - pr * PW;
+            n = t2_n; y = t2_y0 - 1 + pr; x = t2_x0 - 1 + pc;
+            ok = g < PRG && pc < 18 && pr < NB / 16 + 2 && t2_n * p.HoWo < p.M && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        } else {
+            const int q = q0 - (p.qW + 1) + g * 16 + lrow;
+            ok = g < PRG && q >= 0 && q < p.Mq;
+            const int qq = ok ? q : 0;
+            n = (int)fdiv((uint32_t)qq, p.dqHW);
+            const int r = qq - n * p.qHW;
+            y = (int)fdiv((uint32_t)r, p.dqW);
+            x = r - y * p.qW;
+            ok = ok && x < p.W && y < p.H;
+        }
         const long long e = (long long)n * p.in_img_stride + ((long long)y * p.W + x) * p.in_ld + p.in_coff;
         b_off[j] = ok ? (uint32_t)(e * 2) + csw_p : YOLO_INVALID_OFF;
     }
@@ -129,8 +155,10 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     };
     auto issue_weights = [&](int tap, int c, int slot) {
         const uint32_t ka = (uint32_t)(tap * p.cin_chunks + 4 * c) * 16;
+        if (has_a) {
 #pragma unroll
-        for (int j = 0; j < JA; ++j) tap_dma16(rs_w, smem + slot * A_BYTES + (j * NW + wave) * 1024, a_off[j], ka);
+            for (int j = 0; j < JA; ++j) tap_dma16(rs_w, smem + slot * A_BYTES + (j * NW + wave) * 1024, a_off[j], ka);
+        }
     };
 
     float4v acc[TM][TP];
@@ -141,7 +169,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
 
     const int fr = lane & 15, fq = lane >> 4;
     const int a_frag = (wm * TM * 16 + fr) * ROWB + (((fq ^ tap_swz_w(fr)) & 3) << 4);
-    const int rb = wn * TP * 16 + fr;       // patch row of this lane's position for tap (0, 0)
+    const int rb = wn * TP * FROW + fr;     // patch row of this lane's position for tap (0, 0)
 
     auto compute = [&](int slot, int buf, int shift) {
         const unsigned char *A = smem + slot * A_BYTES + a_frag;
@@ -151,7 +179,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
 #pragma unroll
         for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const uint4v *>(A + a * 16 * ROWB);
 #pragma unroll
-        for (int b = 0; b < TP; ++b) fb[b] = *reinterpret_cast<const uint4v *>(B + b * 16 * ROWB);
+        for (int b = 0; b < TP; ++b) fb[b] = *reinterpret_cast<const uint4v *>(B + b * FROW * ROWB);
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -173,12 +201,17 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
             // Wait for the weights of this tap.  Issue order per tap: weights(tap+2), then (tap 0 only) the next
             // patch; younger than weights(tap) are weights(tap+1) and, at taps 1 and 2, that patch.
             const bool last = !more && tap == 8;
+            const bool with_patch = more && (tap == 1 || tap == 2);
             if (last) tap_wait_vm<0>();
-            else if (more && (tap == 1 || tap == 2)) {
-                if (jp_full) tap_wait_vm<JA + JP>();
+            else if (has_a) {
+                if (!with_patch) tap_wait_vm<JA>();
+                else if (jp_full) tap_wait_vm<JA + JP>();
                 else tap_wait_vm<JA + JP - 1>();
+            } else {            // this wave issues patch instructions only
+                if (!with_patch) tap_wait_vm<0>();
+                else if (jp_full) tap_wait_vm<JP>();
+                else tap_wait_vm<JP - 1>();
             }
-            else tap_wait_vm<JA>();
             __builtin_amdgcn_s_barrier();
             {   // weights two taps ahead
                 const int t2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;
@@ -187,7 +220,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
             }
             if (tap == 0 && more) issue_patch(c + 1, buf ^ 1);
             const int kh = tap / 3, kw = tap - 3 * kh;
-            compute(tap % S, buf, kh * p.qW + kw);
+            compute(tap % S, buf, MODE == 2 ? kh * PW + kw : kh * p.qW + kw);
         }
     };
     for (int c = 0; c < C; c += 2) {
@@ -196,7 +229,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     }
     (void)KT;
     const unsigned long long t_loop = p.trace ? wall_clock64() : 0ull;
-    conv_epilogue<T, TM, TP, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
+    conv_epilogue<T, TM, TP, MODE>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
     if (p.trace && tid == 0) {          // YOLO_CONV_TRACE: phase timestamps (100 MHz) + placement of wave 0 of every block
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned long long *r = p.trace + (size_t)blockIdx.x * 8;
@@ -208,12 +241,15 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     }
 }
 
-// variants: 0 = 128 couts x 256 positions, 1 = 256 x 256 (one workgroup per CU), 2 = 128 x 192, 3 = 128 x 128
-// (smaller position tiles fill the 512 workgroup slots of the chip better on small feature maps)
-static const int kTapNB[] = {256, 256, 192, 128};
-static const int kTapPRG[] = {26, 26, 26, 28};
+// variants: 0 = 128 couts x 256 positions, 1 = 256 x 256 (one workgroup per CU), 2 = 128 x 192, 3 = 128 x 128 (smaller
+// position tiles fill the 512 workgroup slots of the chip better on small feature maps), all padded-linear;
+// 4 = 128 x (16 x 16) and 5 = 64 x (16 x 16) 2-D tiles for maps wider than 78 (any width)
+static const int kTapNB[] = {256, 256, 192, 128, 256, 256};
+static const int kTapPRG[] = {26, 26, 26, 28, 27, 27};
+bool conv_tap_is2d(int variant) { return variant >= 4; }
 bool conv_tap_fits(int variant, int W) {
-    if (variant < 0 || variant > 3) return false;
+    if (variant < 0 || variant > 5) return false;
+    if (conv_tap_is2d(variant)) return true;
     return kTapNB[variant] + 2 * W + 4 <= kTapPRG[variant] * 16;
 }
 
@@ -226,6 +262,8 @@ hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
     case 1: hipLaunchKernelGGL((conv3x3_tap_kernel<2, 4, 8, 4, 26, 2>), grid, dim3(512), 0, s, p); break;
     case 2: hipLaunchKernelGGL((conv3x3_tap_kernel<2, 4, 4, 3, 26, 4>), grid, dim3(512), 0, s, p); break;
     case 3: hipLaunchKernelGGL((conv3x3_tap_kernel<2, 4, 4, 2, 28, 4>), grid, dim3(512), 0, s, p); break;
+    case 4: hipLaunchKernelGGL((conv3x3_tap_kernel<2, 4, 4, 4, 27, 4, 2>), grid, dim3(512), 0, s, p); break;
+    case 5: hipLaunchKernelGGL((conv3x3_tap_kernel<1, 8, 4, 2, 27, 4, 2>), grid, dim3(512), 0, s, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -195,6 +195,7 @@ int dma_cfg_bkc(int cfg);
 hipError_t launch_conv_dma(const ConvParams &p, int cfg, hipStream_t s);
 hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s);       // conv_tap.hip: 3x3/1 with tap reuse
 bool conv_tap_fits(int variant, int W);
+bool conv_tap_is2d(int variant);
 const char *dma_cfg_name(int cfg);
 int dma_num_cfgs();
 int dma_cfg_na(int cfg);
