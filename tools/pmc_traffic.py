@@ -21,7 +21,10 @@ def family(name):
     if m:
         v = tuple(int(x) for x in (m.group(1).split(",") if m.lastindex == 1 else m.groups()))
         return "conv_igemm_dma<f16,%s>" % {(2, 4, 4, 4): "128x256,tap9,x2", (2, 4, 8, 4): "256x256,tap9", (2, 4, 4, 3): "128x192,tap9,x2",
-                                           (2, 4, 4, 2): "128x128,tap9,x2"}.get(v[:4], str(v))
+                                           (2, 4, 4, 2): "128x128,tap9,x2"}.get(v[:4], str(v)) if (len(v) < 7 or v[6] == 1) else \
+            "conv_igemm_dma<f16,%s>" % {(2, 4, 4, 4): "128x256,tap9,2d,x2", (1, 8, 4, 2): "64x256,tap9,2d,x2"}.get(v[:4], str(v))
+    if "stem_v3_kernel" in name:
+        return "conv_stem<f16,3-32-64>"
     m = re.search(r"conv_first_kernelI(DF16_|f)Li(\d+)", name)
     if m:
         return "conv_first<%s,%s>" % ("f16" if m.group(1) == "DF16_" else "f32", m.group(2))
