@@ -164,6 +164,13 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     }
 
     // ---- epilogue: bias, leaky, residual, store (conv_common.h) -------------------------------
+    if (p.out_f32 && !p.vec_out && p.outmode == OUT_NORMAL && !p.has_res) {      // head conv: coalesced float32 rows via LDS
+        static_assert(4 * 16 * kStagePitch(TM) * 4 <= 2 * TILE_BYTES, "staging slabs must fit in the tile buffers");
+        // (the loop's last __syncthreads already separates the tile reads from this reuse)
+        conv_epilogue_f32_staged<TM, TP>(p, acc, n0 + wm * (TM * 16), m0 + wn * (TP * 16), lane,
+                                         reinterpret_cast<float *>(smem) + wave * 16 * kStagePitch(TM));
+        return;
+    }
     conv_epilogue<T, TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH, m0 + wn * (TP * 16), fr);
 }
 

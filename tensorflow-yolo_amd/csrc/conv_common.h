@@ -186,6 +186,57 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, float4v (&acc
     }
 }
 
+// Head convs: float32 output with a channel count that is not a multiple of 4 (255 = 3 x 85, 425 = 5 x 85), so the
+// generic epilogue falls back to one scattered 4-byte store per value (64 lanes -> 64 different 4-byte pieces per
+// instruction).  Here each wave transposes its 16 pixels x (4 CH) couts through a private LDS slab and writes every
+// pixel's run of 64 consecutive floats (256 contiguous bytes) with one instruction.  OUT_NORMAL, no residual.
+constexpr int kStagePitch(int TM) { return 16 * TM + 4; }       // floats per pixel row of the slab (4 CH + pad)
+
+template <int TM, int TP, int PADQ = 0>
+__device__ __forceinline__ void conv_epilogue_f32_staged(const ConvParams &p, float4v (&acc)[TM][TP], int cbase_wave, int m_wave,
+                                                         int lane, float *slab) {
+    constexpr int CH = 4 * TM;
+    constexpr int PITCH = kStagePitch(TM);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int cbase = cbase_wave + fq * CH;
+    {
+        float bias[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) bias[i] = p.bias[cbase + i];      // bias is padded to 128 couts
+#pragma unroll
+        for (int b = 0; b < TP; ++b)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = acc[a][b][j] + bias[4 * a + j];
+                    acc[a][b][j] = p.leaky ? fmaxf(0.1f * x, x) : x;
+                }
+    }
+    float *op = reinterpret_cast<float *>(p.out);
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+        int n, rem, oy, ox;
+        const bool ok = conv_decode_pixel<PADQ>(p, m_wave + b * 16 + fr, n, rem, oy, ox);
+        const long long off = (long long)n * p.out_img_stride + (long long)rem * p.out_ld;
+        const int off_lo = (int)(off & 0xffffffffLL), off_hi = (int)(off >> 32), oki = ok ? 1 : 0;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) *reinterpret_cast<float4v *>(slab + fr * PITCH + fq * CH + 4 * a) = acc[a][b];
+        __builtin_amdgcn_wave_barrier();        // LDS executes a wave's instructions in order: the reads below see these writes
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) {
+            if (!__builtin_amdgcn_readlane(oki, pp)) continue;         // wave-uniform
+            const long long po = ((long long)__builtin_amdgcn_readlane(off_hi, pp) << 32) | (unsigned)__builtin_amdgcn_readlane(off_lo, pp);
+#pragma unroll
+            for (int h = 0; h < (4 * CH + 63) / 64; ++h) {
+                const int c = lane + 64 * h;
+                if (c < 4 * CH && cbase_wave + c < p.Cout) op[po + cbase_wave + c] = slab[pp * PITCH + c];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // XCD-aware bijective remap of the linear block id: the 8 XCDs (blocks b, b+8, ... share one) get
 // contiguous ranges of (pixel-tile, cout-tile) so the cout tiles of one pixel tile run back to back
 // on one XCD and share its L2.  Speed only: any placement gives the same result.

@@ -201,6 +201,13 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
     }
 
     if (p.dbg & 4) return;             // experiment: no epilogue
+    if (p.out_f32 && !p.vec_out && p.outmode == OUT_NORMAL && !p.has_res) {      // head conv: coalesced float32 rows via LDS
+        static_assert(8 * 16 * kStagePitch(TM) * 4 <= S * TILE_BYTES, "staging slabs must fit in the ring");
+        __syncthreads();            // every wave is done reading the ring
+        conv_epilogue_f32_staged<TM, TP>(p, acc, n0 + wm * (TM * 16), m0 + wn * (TP * 16), lane,
+                                         reinterpret_cast<float *>(smem) + wave * 16 * kStagePitch(TM));
+        return;
+    }
     conv_epilogue<T, TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH, m0 + wn * (TP * 16), fr);
 }
 
