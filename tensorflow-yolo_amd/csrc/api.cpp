@@ -244,9 +244,17 @@ int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, h
                 p.H = f.in.H; p.W = f.in.W; p.Ho = k.out.H; p.Wo = k.out.W;
                 p.out_ld = k.out.ld; p.out_img_stride = k.out.img_stride;
                 p.in_img_stride = (long long)f.in.H * f.in.W * 3;
+                if (ki + 1 < net->kernels.size() && net->kernels[ki + 1].stem == 3) {      // 1x1 64->32 on the same pixels
+                    const Kernel &t = net->kernels[ki + 1];
+                    p.w3 = net->dev_weights + t.w_off;
+                    p.b3 = reinterpret_cast<const float *>(net->dev_weights + t.b_off);
+                    p.out3 = P.view_ptr(t.out);
+                    p.out3_ld = t.out.ld; p.out3_img_stride = t.out.img_stride;
+                }
                 e = launch_stem(p, batch, s);
                 break;
             }
+            if (k.stem == 3) break;     // computed by the stem kernel
             ConvParams p;
             int rc = make_conv_params(net, k, P, batch, p);
             if (rc) return rc;
@@ -394,12 +402,24 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         out->flops = 2.0 * li.H * li.W * k.cout * k.ksize * k.ksize * k.cin;
         out->bytes = (double)k.in.H * k.in.W * k.cin * net->esize + elems(k.out) * esz(k.out) + (k.has_res ? elems(k.in2) * net->esize : 0.0);
         out->weight_bytes = (double)k.cout * k.ksize * k.ksize * k.cin * net->esize + 4.0 * k.cout;
+        if (k.stem == 3) {          // no launch of its own
+            out->flops = 0; out->bytes = 0; out->weight_bytes = 0;
+            snprintf(out->name, sizeof out->name, "conv_igemm<fused into conv_stem>");
+            return YOLO_OK;
+        }
         if (k.stem == 2) {
             const Kernel &f = net->kernels[kernel - 1];
             out->flops += 2.0 * f.out.H * f.out.W * f.cout * 27;
             out->bytes = (double)f.in.H * f.in.W * 3 * 4 + elems(k.out) * esz(k.out);
             out->weight_bytes += 28.0 * f.cout * 4;
             snprintf(out->name, sizeof out->name, "conv_stem<f16,3-32-64>");
+            if (kernel + 1 < (int)net->kernels.size() && net->kernels[kernel + 1].stem == 3) {
+                const Kernel &t3 = net->kernels[kernel + 1];
+                out->flops += 2.0 * li.H * li.W * t3.cout * t3.cin;
+                out->bytes += elems(t3.out) * esz(t3.out);
+                out->weight_bytes += (double)t3.cout * t3.cin * net->esize + 4.0 * t3.cout;
+                snprintf(out->name, sizeof out->name, "conv_stem<f16,3-32-64-32>");
+            }
             return YOLO_OK;
         }
         int tile = 0;       // which kernel runs at max_batch (bench.py runs at max_batch)
@@ -442,7 +462,7 @@ int yolo_net_autotune(yolo_net *net, const float *in_dev, int batch, void *strea
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     for (Kernel &k : net->kernels) {
-        if (k.kind != K_CONV || k.stem == 2 || !dma_eligible(net, k)) continue;
+        if (k.kind != K_CONV || k.stem >= 2 || !dma_eligible(net, k)) continue;
         ConvParams p;
         rc = make_conv_params(net, k, P, batch, p);
         if (rc) break;

@@ -395,6 +395,14 @@ struct Planner {
                     k.stem = 2;
                     k.note += " fused with the first layer (stem.hip): the 32-channel tensor stays in LDS";
                 }
+                // ... and the 1x1 64->32 conv behind the stem (Darknet-53 layer 3) is computed by the stem kernel too
+                if (i == 3 && net->kernels.size() >= 2 && net->kernels.back().stem == 2 && s == 2 && d.ksize == 1 && d.stride == 1 &&
+                    d.filters == 32 && cin == 64 && d.leaky && f.kind == 0 && !has_head[i] && !k.out.f32 && k.out.ld % epc == 0 &&
+                    (k.out.base + k.out.coff) % epc == 0 && k.out.img_stride % epc == 0 && k.in.ld == net->kernels.back().out.ld &&
+                    k.in.coff == net->kernels.back().out.coff && k.in.buf == net->kernels.back().out.buf && !getenv("YOLO_NO_STEM3")) {
+                    k.stem = 3;
+                    k.note += " computed inside the stem kernel (no launch)";
+                }
                 net->kernels.push_back(k);
                 L[key].view = k.out; L[key].materialised = true;
                 if (key != i) { L[i].materialised = false; }

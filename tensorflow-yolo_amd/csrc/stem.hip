@@ -14,7 +14,10 @@
 //            padding), fp16, written as 64-byte rows of an LDS patch whose columns are de-interleaved by parity, so
 //            that the stride-2 taps of 16 consecutive outputs read 16 consecutive rows;
 //   phase 2  layer 2: 9 taps x one k-step, A = weight tile of the tap, B = patch rows (shift-invariant swizzle of
-//            conv_tap.hip), bias + leaky, 32-byte NHWC stores (a lane owns 16 contiguous couts).
+//            conv_tap.hip), bias + leaky, 32-byte NHWC stores (a lane owns 16 contiguous couts);
+//   phase 3  (when the planner hands it over) the 1x1 64->32 conv + BN + leaky that follows in Darknet-53, straight
+//            from the lane's own fp16 outputs as MFMA B operand (no LDS: the k order of an MFMA is free), saving the
+//            1x1 kernel its 378 MB re-read of the tensor just written.
 #include "conv_common.h"
 
 namespace yolo {
@@ -45,15 +48,17 @@ constexpr int EVEN_COLS = (P1X + 1) / 2;    // 17 even columns come first in a p
 constexpr int W2_BYTES = 9 * 64 * 64;
 constexpr int P_BYTES = NGRP * 16 * 64;
 constexpr int IN_BYTES = INY * IN_LD * 2;
+constexpr int BIAS_BYTES = (64 + 32) * 4;  // layer-2 and layer-3 biases (read per tile: keeps 24 VGPRs free)
 
 }  // namespace
 
 __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
     typedef _Float16 T;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[W2_BYTES + P_BYTES + IN_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[W2_BYTES + P_BYTES + IN_BYTES + BIAS_BYTES];
     unsigned char *const sW = smem;
     unsigned char *const sP = smem + W2_BYTES;
     T *const sIn = reinterpret_cast<T *>(smem + W2_BYTES + P_BYTES);
+    float *const sBias = reinterpret_cast<float *>(smem + W2_BYTES + P_BYTES + IN_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -75,7 +80,7 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
     }
     // layer-1 weights as MFMA A fragments: tile t, row rho = fr holds channel 8*(rho>>2) + 4t + (rho&3); k = 8 fq + j
     uint4v a1[2];
-    float bias1[8], bias2[16];
+    float bias1[8];
     {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -91,8 +96,8 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) bias1[i] = p.b1[8 * fq + i];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) bias2[i] = p.b2[16 * fq + i];
+        if (tid < 64) sBias[tid] = p.b2[tid];
+        else if (tid < 96 && p.w3) sBias[tid] = p.b3[tid - 64];
     }
     // per-lane K decode of the B fragment: k = 8 fq + j -> offset kh * IN_LD + (kw * 3 + c) inside the input patch
     int koff[8];
@@ -103,6 +108,19 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
         koff[j] = k < 27 ? kh * IN_LD + (k - 9 * kh) : 0;
     }
     const int a_frag = fr * 64 + (((fq ^ stem_swz_w(fr)) & 3) << 4);
+    // optional layer 3 (1x1 64->32): the lane already owns 16 channels of its pixel after layer 2, and an MFMA sums over
+    // k in any order, so k-step ks takes channels 16 fq + 8 ks + j straight from the lane's registers (no LDS round
+    // trip); weight tile t, row rho = fr holds cout 8*(rho>>2) + 4t + (rho&3) -> the lane ends up with 8 contiguous couts
+    uint4v a3[2][2];
+    if (p.w3) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int co = 8 * (fr >> 2) + 4 * t + (fr & 3);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                a3[t][ks] = *reinterpret_cast<const uint4v *>(reinterpret_cast<const unsigned char *>(p.w3) + co * 128 + (16 * fq + 8 * ks) * 2);
+        }
+    }
 
     // input patch of a tile: thread -> NIN elements (row, col) of the 19 x 105 float block, fetched into registers
     // one tile ahead (the HBM latency hides behind the previous tile's two MFMA phases)
@@ -185,40 +203,61 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
         __syncthreads();    // patch P complete; the input patch may be overwritten
 
         // ---- phase 2: layer 2, wave = output row oy0 + wave, 16 pixels x 64 couts ------------------
-        uint4v fb[9];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {     // all nine pixel fragments first: their latency overlaps
-            const int kh = tap / 3, kw = tap - 3 * kh;
-            const int rowP = (2 * wave + kh) * P1X + (kw & 1) * EVEN_COLS + fr + (kw >> 1);
-            fb[tap] = *reinterpret_cast<const uint4v *>(sP + rowP * 64 + ((fq ^ stem_swz_p(rowP)) << 4));
-        }
         float4v acc[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) acc[a] = float4v{0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < 4; ++a) acc[a] = *reinterpret_cast<const float4v *>(sBias + fq * 16 + 4 * a);     // bias as MFMA C input
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            uint4v fa[4];
+        for (int kh = 0; kh < 3; ++kh) {        // three pixel fragments at a time: their latency overlaps
+            uint4v fb[3];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const uint4v *>(sW + tap * 4096 + a * 1024 + a_frag);
+            for (int kw = 0; kw < 3; ++kw) {
+                const int rowP = (2 * wave + kh) * P1X + (kw & 1) * EVEN_COLS + fr + (kw >> 1);
+                fb[kw] = *reinterpret_cast<const uint4v *>(sP + rowP * 64 + ((fq ^ stem_swz_p(rowP)) << 4));
+            }
 #pragma unroll
-            for (int a = 0; a < 4; ++a) acc[a] = mma_chunk<T>(fa[a], fb[tap], acc[a]);
+            for (int kw = 0; kw < 3; ++kw) {
+                uint4v fa[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const uint4v *>(sW + (kh * 3 + kw) * 4096 + a * 1024 + a_frag);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a] = mma_chunk<T>(fa[a], fb[kw], acc[a]);
+            }
         }
         const int oy = oy0 + wave, ox = ox0 + fr;
-        if (oy < p.Ho && ox < p.Wo) {
-            T o[16];
+        const bool valid = oy < p.Ho && ox < p.Wo;
+        T o[16];
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = acc[a][j] + bias2[4 * a + j];
-                    o[4 * a + j] = (T)fmaxf(0.1f * v, v);
-                }
-            T *op = reinterpret_cast<T *>(p.out) + (long long)n * p.out_img_stride + ((long long)oy * p.Wo + ox) * p.out_ld + fq * 16;
-            uint4v u0, u1;
-            __builtin_memcpy(&u0, o, 16);
-            __builtin_memcpy(&u1, o + 8, 16);
+            for (int j = 0; j < 4; ++j) {
+                const float v = acc[a][j];
+                o[4 * a + j] = (T)fmaxf(0.1f * v, v);
+            }
+        uint4v u0, u1;
+        __builtin_memcpy(&u0, o, 16);
+        __builtin_memcpy(&u1, o + 8, 16);
+        const long long pix = (long long)oy * p.Wo + ox;
+        if (valid) {
+            T *op = reinterpret_cast<T *>(p.out) + (long long)n * p.out_img_stride + pix * p.out_ld + fq * 16;
             *reinterpret_cast<uint4v *>(op) = u0;
             *reinterpret_cast<uint4v *>(op + 8) = u1;
+        }
+        if (p.w3) {         // (wave-uniform) layer 3 on the same 16 pixels; operands = the fp16 values just stored
+            float4v d0 = mma_chunk<T>(a3[0][0], u0, *reinterpret_cast<const float4v *>(sBias + 64 + 8 * fq));
+            float4v d1 = mma_chunk<T>(a3[1][0], u0, *reinterpret_cast<const float4v *>(sBias + 64 + 8 * fq + 4));
+            d0 = mma_chunk<T>(a3[0][1], u1, d0);
+            d1 = mma_chunk<T>(a3[1][1], u1, d1);
+            T o3[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v0 = d0[j], v1 = d1[j];
+                o3[j] = (T)fmaxf(0.1f * v0, v0);
+                o3[4 + j] = (T)fmaxf(0.1f * v1, v1);
+            }
+            uint4v u3;
+            __builtin_memcpy(&u3, o3, 16);
+            if (valid)
+                *reinterpret_cast<uint4v *>(reinterpret_cast<T *>(p.out3) + (long long)n * p.out3_img_stride + pix * p.out3_ld + fq * 8) = u3;
         }
     }
 }

@@ -125,6 +125,11 @@ struct StemParams {            // stem.hip: fused conv 3x3/1 3->32 + conv 3x3/2 
     const void *w2;            // second layer, K_CONV packing: [Cout_pad][wrow2 bytes] fp16, K = (kh, kw, 32 cin)
     const float *b2;           // [Cout_pad]
     void *out;                 // fp16 NHWC view [B,H/2,W/2,64]
+    const void *w3;            // optional third layer (1x1 64->32, BN + leaky) on the same pixels: [Cout_pad][128 B] fp16, or null
+    const float *b3;
+    void *out3;                // fp16 NHWC view [B,H/2,W/2,32]
+    int out3_ld;
+    long long out3_img_stride;
     uint32_t w2_bytes, wrow2;
     int H, W, Ho, Wo, out_ld;
     long long in_img_stride, out_img_stride;
@@ -218,7 +223,8 @@ struct Kernel {
     int ksize = 0, stride = 0, cout = 0, cin = 0, cin_s = 0, leaky = 0, outmode = 0, has_res = 0;
     int cfg = 0, perchunk = 0, cpt = 0, ktiles = 0;
     int tile = -1;             // conv_dma tile id chosen by yolo_net_autotune (-1: heuristic)
-    int stem = 0;              // 1: first-layer kernel fused away into the next conv; 2: this conv runs as stem.hip with it
+    int stem = 0;              // 1: first-layer kernel fused away into the next conv; 2: this conv runs as stem.hip with it;
+                               // 3: this 1x1 conv is computed by the stem kernel in front of it (no launch)
     size_t w_off = 0, b_off = 0, w_bytes = 0;   // inside the device weight blob
     size_t w_src = 0;                           // first float of this conv in the Darknet stream
     int batch_norm = 0;

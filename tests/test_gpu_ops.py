@@ -211,9 +211,18 @@ def test_fused_stem(shape):
     x = synth.synthetic_input(B, H, W, 3, seed=31)
     eng = check_graph(g, x, "fp16", seed=6)
     names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
-    assert ("conv_stem" in names) == (H % 2 == 0 and W % 2 == 0), names
+    assert ("conv_stem<f16,3-32-64-32>" in names) == (H % 2 == 0 and W % 2 == 0), names       # incl. the 1x1 64->32 behind it
     eng32 = check_graph(g, x, "fp32", seed=6)
     assert "conv_stem" not in " ".join(ki.name.decode() for ki in eng32.kernel_infos())
+    # a different third layer stays a kernel of its own: two-layer stem
+    g2 = new_graph(H, W, 3)
+    g2.append(PL.conv2d_bn_act(g2[-1].out, 32, 3, 1))
+    g2.append(PL.conv2d_bn_act(g2[-1].out, 64, 3, 2))
+    g2.append(PL.conv2d_bn_act(g2[-1].out, 64, 1, 1))
+    g2.append(PL.max_pool2d(g2[-1].out, 2, stride=1))
+    eng2 = check_graph(g2, x, "fp16", seed=8)
+    names2 = " ".join(ki.name.decode() for ki in eng2.kernel_infos())
+    assert ("conv_stem<f16,3-32-64>" in names2) == (H % 2 == 0 and W % 2 == 0) and "3-32-64-32" not in names2, names2
 
 
 @pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13])
