@@ -193,6 +193,7 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
             else if (S >= 3 && after >= 1) wait_vmcnt<JB>();
             else wait_vmcnt<0>();
         }
+        __builtin_amdgcn_sched_barrier(0);  // no ds_read / MFMA of the previous tile moves below the barrier (see conv_tap.hip)
         __builtin_amdgcn_s_barrier();       // tile kt visible to every wave; stage `fill` no longer read
         if (kt + S - 1 < KT && !(p.dbg & 1)) issue_tile(kt + S - 1, fill);
         if (!(p.dbg & 2)) compute(stage);

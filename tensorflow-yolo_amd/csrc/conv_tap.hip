@@ -212,6 +212,11 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
                 else if (jp_full) tap_wait_vm<JP>();
                 else tap_wait_vm<JP - 1>();
             }
+            // Nothing is scheduled across the barrier: every ds_read of this tap is consumed by an MFMA before the wave
+            // arrives, so a slot is provably idle when another wave's DMA (issued after the barrier) overwrites it.
+            // (The compiler otherwise sinks the last fragment reads + MFMAs below the barrier: 0.5 % faster, but safe
+            // only by timing.)
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             {   // weights two taps ahead
                 const int t2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;
