@@ -233,9 +233,11 @@ static const DmaCfg kCfgs[] = {
     {128, 128, 2, 1.00f, "128x128,tap9,x2", 4},        // 11
     {128, 256, 2, 1.00f, "128x256,tap9,2d,x2", 4},     // 12: 2-D 16x16 tiles for maps wider than 78
     {64, 256, 2, 1.00f, "64x256,tap9,2d,x2", 4},       // 13: ... and Cout <= 64
+    {128, 128, 3, 1.00f, "128x128,K32,S3,x3", 4},      // 14: conv_dma again: 48 KiB LDS, <= 80 VGPRs: three workgroups per CU (short-K 1x1 layers)
 };
-static const int kNumCfgs = 14;
-static const int kFirstTapCfg = 8;
+static const int kNumCfgs = 15;
+static const int kFirstTapCfg = 8, kLastTapCfg = 13;
+static inline bool is_tap_cfg(int cfg) { return cfg >= kFirstTapCfg && cfg <= kLastTapCfg; }
 
 // Pick the block tile that minimises rounds x tile time on 256 CUs (tail quantisation matters:
 // e.g. 38x38x512 at batch 32 is 362 tiles of 256x256 = 2 rounds at 71 % but 722 of 256x128 = 3 at 94 %).
@@ -244,8 +246,8 @@ bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok, int ksize, int
     if (cfg < 0 || cfg >= kNumCfgs) return false;
     const DmaCfg &k = kCfgs[cfg];
     if (cin_chunks % k.bkc) return false;
-    if (cfg >= kFirstTapCfg && (ksize != 3 || stride != 1 || !conv_tap_fits(cfg - kFirstTapCfg, W))) return false;
-    if (k.na == 64) return cout <= 64 && (cfg < kFirstTapCfg || cout > 32);
+    if (is_tap_cfg(cfg) && (ksize != 3 || stride != 1 || !conv_tap_fits(cfg - kFirstTapCfg, W))) return false;
+    if (k.na == 64) return cout <= 64 && (!is_tap_cfg(cfg) || cout > 32);
     return k.na <= (cout + 127) / 128 * 128 && cout > 64;
 }
 
@@ -274,6 +276,7 @@ static const TileCost kCost[] = {
     {0.76f, 0.90f, 0.63f, 6.9f},        // 11: 128x128 tap reuse, two per CU
     {0.90f, 1.10f, 0.60f, 17.0f},       // 12: 128x256 tap reuse, 2-D tiles (152x152 64->128: 175 us, 76x76: 117, 38x38: 138)
     {1.00f, 1.00f, 0.60f, 5.8f},        // 13: 64x256 tap reuse, 2-D tiles (chosen by rule below)
+    {1.10f, 1.50f, 0.70f, 8.0f},        // 14: 128x128 K32 S3, three per CU: 1x1 layers only (short K, memory / latency bound)
 };
 
 int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W) {
@@ -290,16 +293,17 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
     double best_t = 1e300;
     for (int c = 0; c < kNumCfgs; ++c) {
         if (c == 12 && W <= 110) continue;      // the padded-linear tiles fit and measured faster (104x104: 70 vs 84 us)
+        if (c == 14 && taps != 1) continue;     // measured 10-20 % slower than the larger tiles on every 3x3 layer
         if (c == 7 || c == 13 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
         const DmaCfg &k = kCfgs[c];
         // tap-reuse tiles walk the padded position grid: (H+1)(W+1) positions per image (square maps assumed here)
         long long Meff = M;
-        if (c >= kFirstTapCfg) {
+        if (is_tap_cfg(c)) {
             if (conv_tap_is2d(c - kFirstTapCfg)) { const long long t = (W + 15) / 16; Meff = (long long)M * t * t * 256 / ((long long)W * W); }
             else Meff = (long long)M * (W + 1) * (W + 1) / ((long long)W * W);
         }
         const long long blocks = (Meff + k.nb - 1) / k.nb * ((cout + k.na - 1) / k.na);
-        const long long slots = 256LL * k.slots_per_cu;
+        const long long slots = 256LL * k.slots_per_cu;     // resident workgroups on the chip
         // one workgroup per CU: whole rounds; two per CU: the dispatcher back-fills, the tail costs ~half a round
         double rounds, a;
         if (k.slots_per_cu == 1) {
@@ -333,7 +337,7 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     p.n_blocks = (int)blocks;
     conv_set_divisors(p, p.cin_chunks / k.bkc);
-    if (cfg >= kFirstTapCfg) {      // padded-linear position grid: one shared pad column per row, one pad row per image
+    if (is_tap_cfg(cfg)) {          // padded-linear position grid: one shared pad column per row, one pad row per image
         long long mq;
         if (conv_tap_is2d(cfg - kFirstTapCfg)) {     // 16 x 16 tiles: qW = tiles per tile row, qHW = tiles per image
             p.qW = (p.W + 15) / 16;
@@ -384,6 +388,7 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
     case 5: hipLaunchKernelGGL((conv_igemm_dma_kernel<4, 2, 4, 4, 3, 4, 4>), grid, block, 0, s, p); break;
     case 6: hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 4, 4, 3, 4, 4>), grid, block, 0, s, p); break;
     case 7: hipLaunchKernelGGL((conv_igemm_dma_kernel<1, 8, 4, 4, 2, 4, 4>), grid, block, 0, s, p); break;
+    case 14: hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 4, 2, 3, 4, 6>), grid, block, 0, s, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

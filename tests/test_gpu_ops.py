@@ -278,7 +278,7 @@ def test_tap_reuse_conv_shapes(shape, tile, monkeypatch):
         assert "tap9" in names, names
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 14])
 def test_every_dma_tile_config(tile, monkeypatch):
     """each LDS-DMA tile shape of conv_dma.hip, forced through YOLO_CONV_TILE (read at every launch; a tile
     that is not valid for a layer falls back to the heuristic), on a graph with 3x3/1, 3x3/2, 1x1, residual,
