@@ -77,3 +77,36 @@ def test_autotune_keeps_results():
     assert rel_err(after, before) <= 2e-2
     names = {ki.name.decode() for ki in eng.kernel_infos()}
     assert any(n.startswith("conv_igemm") for n in names)
+
+
+def test_full_size_v3_608_batch32():
+    """BASELINE.json's headline shape (YOLOv3 608x608, batch 32, fp16) through the production kernels (stem, 2-D and
+    padded-linear tap-reuse tiles at 304/152/76/38/19): (a) two images against the fp16-emulating oracle; (b) the same
+    two images repeated 16x as a batch of 32 -- equal images must give bit-identical logits whatever tile they land
+    in (a pixel's K order does not depend on its position), and agree with the batch-2 run within fp16
+    summation-order noise (the tile, and so the K order, may differ between batch 2 and batch 32)."""
+    import torch
+    from tensorflow_yolo_amd.net import engine
+    net, nc = build("v3", 608)
+    w = synth.darknet_stream(net, seed=5, num_classes=nc)
+    x2 = synth.synthetic_input(2, 608, 608, 3, seed=9)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, threads))             # MKL-DNN convs on a 128-core host are fastest at ~32 threads
+    try:
+        want16 = FR.forward(to_oracle(net), w, x2, storage="fp16")
+    finally:
+        torch.set_num_threads(threads)
+    eng = engine.HipNetwork(net, dtype="fp16", max_batch=32)
+    eng.load_weights(w)
+    got2 = eng.forward(x2).cpu().numpy()
+    e16 = rel_err(got2, want16)
+    print("v3-608 b2 fp16 vs fp16-emulating oracle: rel %.2e" % e16)
+    assert e16 <= 2e-2, e16
+    names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
+    assert "conv_stem" in names and "tap9,x2" in names and "tap9,2d" in names, names
+    x32 = np.concatenate([x2] * 16, axis=0)
+    got32 = eng.forward(x32).cpu().numpy()
+    assert got32.shape[0] == 32
+    for i in range(2, 32):
+        assert np.array_equal(got32[i], got32[i % 2]), "image %d differs from its twin" % i
+    assert rel_err(got32[:2], got2) <= 5e-3
