@@ -81,7 +81,8 @@ typedef struct yolo_net_options {
     int32_t dtype;          /* enum yolo_dtype: storage/operand type (accumulation is f32)     */
     int32_t max_batch;      /* buffers are planned for this many images                        */
     int32_t keep_all;       /* 1: no activation-buffer reuse, so yolo_net_read_layer works     */
-    int32_t cand_capacity;  /* candidates per image the decode stage can hold (0 -> 4096)      */
+    int32_t cand_capacity;  /* candidates per image the decode stage can hold (0 -> 4096; up to
+                             * 4096 sort + NMS run in LDS, up to 65536 on global-memory slabs)  */
     int32_t max_boxes;      /* records per image written by detect / decode_nms (0 -> 256)     */
     int32_t reserved[3];
 } yolo_net_options;

@@ -38,9 +38,9 @@ int yolo_net_create(const yolo_layer_desc *layers, int n_layers, const yolo_net_
     net->opt = *opt;
     if (net->opt.cand_capacity <= 0) net->opt.cand_capacity = 4096;
     if (net->opt.max_boxes <= 0) net->opt.max_boxes = 256;
-    if (nms_lds_bytes(net->opt.cand_capacity) > 160 * 1024) {
+    if (net->opt.cand_capacity > 65536) {
         delete net;
-        return fail(YOLO_ERR_ARG, "cand_capacity too large for the 160 KiB LDS sort (max 4096)");
+        return fail(YOLO_ERR_ARG, "cand_capacity above 65536 (16-bit sort indices)");
     }
     std::string err;
     int rc = YOLO_ERR_PLAN;
@@ -338,7 +338,7 @@ void fill_decode(const yolo_head_desc &h, DecodeParams &dp) {
 
 int run_decode_nms(const yolo_head_desc &h, const float *logits, int batch, double thr, double iou, int mode, int cap,
                    int max_boxes, unsigned char *cand, int *cand_count, yolo_box *boxes, int32_t *counts, int32_t *status,
-                   int32_t *keep_idx, hipStream_t s) {
+                   int32_t *keep_idx, hipStream_t s, unsigned char *nms_scratch = nullptr) {
     DecodeParams dp;
     memset(&dp, 0, sizeof dp);
     fill_decode(h, dp);
@@ -355,6 +355,7 @@ int run_decode_nms(const yolo_head_desc &h, const float *logits, int batch, doub
     np.cap = cap; np.max_boxes = max_boxes; np.mode = mode;
     np.iou_threshold = iou;
     np.boxes = boxes; np.counts = counts; np.status = status; np.keep_idx = keep_idx;
+    np.scratch = nms_scratch; np.scratch_stride = nms_scratch_bytes(cap);
     HIP_TRY(launch_nms(np, batch, s));
     return YOLO_OK;
 }
@@ -503,7 +504,7 @@ int yolo_net_detect(yolo_net *net, const float *in_dev, int batch, double thresh
     if (rc) return rc;
     return run_decode_nms(net->head, logits, batch, threshold, iou_threshold, nms_mode, net->opt.cand_capacity,
                           net->opt.max_boxes, net->dev_ws + net->cand_off, reinterpret_cast<int *>(net->dev_ws + net->count_off),
-                          boxes_dev, counts_dev, status_dev, nullptr, s);
+                          boxes_dev, counts_dev, status_dev, nullptr, s, net->dev_ws + net->nms_off);
 }
 
 int yolo_net_read_layer(yolo_net *net, int layer, int batch, float *host_out, size_t n) {
@@ -536,7 +537,8 @@ size_t yolo_decode_scratch_bytes(const yolo_head_desc *head, int batch, int cand
     (void)head;
     if (batch <= 0) return 0;
     if (cand_capacity <= 0) cand_capacity = 4096;
-    return ((sizeof(Candidate) * (size_t)cand_capacity * batch + 255) & ~(size_t)255) + ((sizeof(int) * (size_t)batch + 255) & ~(size_t)255);
+    return ((sizeof(Candidate) * (size_t)cand_capacity * batch + 255) & ~(size_t)255) + ((sizeof(int) * (size_t)batch + 255) & ~(size_t)255) +
+           nms_scratch_bytes(cand_capacity) * (size_t)batch;
 }
 
 int yolo_decode_nms(const yolo_head_desc *head, const float *logits_dev, int batch, double threshold, double iou_threshold,
@@ -549,12 +551,13 @@ int yolo_decode_nms(const yolo_head_desc *head, const float *logits_dev, int bat
     std::string err;
     int rc = check_head(head, 0, err);
     if (rc) return fail(rc, "yolo_decode_nms: " + err);
-    if (nms_lds_bytes(cand_capacity) > 160 * 1024) return fail(YOLO_ERR_ARG, "yolo_decode_nms: cand_capacity above 4096");
+    if (cand_capacity > 65536) return fail(YOLO_ERR_ARG, "yolo_decode_nms: cand_capacity above 65536");
     if (scratch_bytes < yolo_decode_scratch_bytes(head, batch, cand_capacity)) return fail(YOLO_ERR_ARG, "yolo_decode_nms: scratch too small");
     unsigned char *cand = static_cast<unsigned char *>(scratch_dev);
     int *cnt = reinterpret_cast<int *>(cand + ((sizeof(Candidate) * (size_t)cand_capacity * batch + 255) & ~(size_t)255));
+    unsigned char *slabs = reinterpret_cast<unsigned char *>(cnt) + ((sizeof(int) * (size_t)batch + 255) & ~(size_t)255);
     return run_decode_nms(*head, logits_dev, batch, threshold, iou_threshold, nms_mode, cand_capacity, max_boxes, cand, cnt,
-                          boxes_dev, counts_dev, status_dev, nullptr, static_cast<hipStream_t>(stream));
+                          boxes_dev, counts_dev, status_dev, nullptr, static_cast<hipStream_t>(stream), slabs);
 }
 
 int yolo_nms_host(const double *xywh, const float *prob, const int32_t *class_idx, int n, double iou_threshold, int nms_mode,
@@ -562,7 +565,7 @@ int yolo_nms_host(const double *xywh, const float *prob, const int32_t *class_id
     if (n < 0 || !n_keep || (n && (!xywh || !prob || !class_idx || !keep_idx))) return fail(YOLO_ERR_ARG, "yolo_nms_host: null argument");
     *n_keep = 0;
     if (n == 0) return YOLO_OK;                      // base.py:196-197
-    if (n > 4096) return fail(YOLO_ERR_OVERFLOW, "yolo_nms_host: more than 4096 boxes");
+    if (n > 65536) return fail(YOLO_ERR_OVERFLOW, "yolo_nms_host: more than 65536 boxes");
     std::vector<Candidate> c(n);
     for (int i = 0; i < n; ++i) {
         c[i].x = (float)xywh[4 * i]; c[i].y = (float)xywh[4 * i + 1]; c[i].w = xywh[4 * i + 2]; c[i].h = xywh[4 * i + 3];
@@ -570,7 +573,7 @@ int yolo_nms_host(const double *xywh, const float *prob, const int32_t *class_id
     }
     unsigned char *dev = nullptr;
     const size_t cb = sizeof(Candidate) * (size_t)n, bb = sizeof(yolo_box) * (size_t)n, ib = sizeof(int) * (size_t)n;
-    const size_t total = ((cb + 255) & ~(size_t)255) + ((bb + 255) & ~(size_t)255) + ((ib + 255) & ~(size_t)255) + 768;
+    const size_t total = ((cb + 255) & ~(size_t)255) + ((bb + 255) & ~(size_t)255) + ((ib + 255) & ~(size_t)255) + 768 + nms_scratch_bytes(n);
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dev), total));
     unsigned char *d_c = dev, *d_b = d_c + ((cb + 255) & ~(size_t)255), *d_i = d_b + ((bb + 255) & ~(size_t)255);
     int *d_cnt = reinterpret_cast<int *>(d_i + ((ib + 255) & ~(size_t)255));    // [count, kept, status] 256 B apart
@@ -585,6 +588,8 @@ int yolo_nms_host(const double *xywh, const float *prob, const int32_t *class_id
         np.boxes = reinterpret_cast<yolo_box *>(d_b);
         np.counts = d_cnt + 64; np.status = d_cnt + 128;
         np.keep_idx = reinterpret_cast<int *>(d_i);
+        np.scratch = reinterpret_cast<unsigned char *>(d_cnt) + 768;      // only used above 4096 boxes
+        np.scratch_stride = nms_scratch_bytes(n);
         hipError_t e = launch_nms(np, 1, nullptr);
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) { rc = fail(YOLO_ERR_HIP, std::string("yolo_nms_host: ") + hipGetErrorString(e)); break; }

@@ -74,9 +74,14 @@ __device__ __forceinline__ unsigned orderable(float f) {        // monotone floa
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// LDS carve (dynamic, 16-byte aligned): idx u16[n2] | union { key u64[n2] ; boxes } | kept u16[cap]
+// Working storage carve (16-byte aligned): idx u16[n2] | union { key u64[n2] ; boxes } | kept u16[cap].
+// Up to 4096 candidates per image it lives in LDS (dynamic); above (GLOBAL: up to 65536, e.g. a mAP-style
+// threshold of 0.005 on 22 743 rows) the same algorithm runs on a per-image slab of global memory that stays in L2
+// (one workgroup per image either way: __syncthreads orders the slab accesses inside the CU).
+extern __shared__ __attribute__((aligned(16))) unsigned char nms_dyn_lds[];
+template <bool GLOBAL>
 __global__ void __launch_bounds__(1024) nms_kernel(const NmsParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char *lds = GLOBAL ? p.scratch + (size_t)blockIdx.x * p.scratch_stride : nms_dyn_lds;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
@@ -199,15 +204,25 @@ hipError_t launch_decode(const DecodeParams &p, int batch, hipStream_t s) {
 
 hipError_t launch_nms(const NmsParams &p, int batch, hipStream_t s) {
     const size_t lds = nms_lds_bytes(p.cap);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 160 * 1024) {         // global-memory slabs
+        if (p.cap > 65536 || !p.scratch || p.scratch_stride < lds) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(nms_kernel<true>, dim3((unsigned)batch), dim3(1024), 0, s, p);
+        return hipGetLastError();
+    }
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL(nms_kernel, dim3((unsigned)batch), dim3(1024), lds, s, p);
+    hipLaunchKernelGGL(nms_kernel<false>, dim3((unsigned)batch), dim3(1024), lds, s, p);
     return hipGetLastError();
+}
+
+// bytes of global scratch per image the NMS needs for this capacity (0: the LDS path is used)
+size_t nms_scratch_bytes(int cap) {
+    const size_t lds = nms_lds_bytes(cap);
+    return lds > 160 * 1024 ? ((lds + 255) & ~(size_t)255) : 0;
 }
 
 }  // namespace yolo

@@ -188,6 +188,8 @@ struct NmsParams {
     int *counts;
     int *status;
     int *keep_idx;             // optional [B][max_boxes]: candidate index of each survivor
+    unsigned char *scratch;    // cap > 4096: [B][scratch_stride] bytes of global working storage (nms_scratch_bytes)
+    size_t scratch_stride;
 };
 
 // ---- launchers (kernels.hip / detect.hip) ------------------------------------------------
@@ -212,6 +214,7 @@ hipError_t launch_eltwise(const EltParams &p, int dtype, hipStream_t s);
 hipError_t launch_decode(const DecodeParams &p, int batch, hipStream_t s);
 hipError_t launch_nms(const NmsParams &p, int batch, hipStream_t s);
 size_t nms_lds_bytes(int cap);
+size_t nms_scratch_bytes(int cap);
 
 // ---- plan -----------------------------------------------------------------------------------
 struct Kernel {
@@ -253,7 +256,7 @@ struct yolo_net {
     size_t weight_count = 0;       // floats in the Darknet stream
     size_t weights_bytes = 0;
     size_t act_bytes = 0;          // activation part of the workspace
-    size_t logits_off = 0, cand_off = 0, count_off = 0;
+    size_t logits_off = 0, cand_off = 0, count_off = 0, nms_off = 0;   // nms_off: global NMS slabs (cand_capacity > 4096)
     size_t workspace_bytes = 0;
     size_t out_count = 0;          // floats per image of the head output
     double flops_per_image = 0;
