@@ -224,7 +224,7 @@ def main():
                        "boxes_per_image_last_step": round(float(nboxes.mean()), 1),
                        "forward_gflop_per_image": round(eng.flops_per_image / 1e9, 3)},
             "roofline": roof,
-            "forward_frac_of_mfma_peak": round(eng.flops_per_image * total_images / elapsed / 1e12 / PEAK[dtype], 4),
+            "forward_frac_of_mfma_peak": round(eng.flops_per_image * total_images / elapsed / 1e12 / (PEAK[dtype] * world), 4),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(kind, size, w, anchors, ncls)
