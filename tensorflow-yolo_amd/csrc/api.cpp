@@ -269,6 +269,7 @@ int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, h
             p.bias = reinterpret_cast<const float *>(net->dev_weights + k.b_off);
             p.out = P.view_ptr(k.out);
             p.H = k.in.H; p.W = k.in.W; p.Cout = k.cout; p.out_ld = k.out.ld; p.leaky = k.leaky;
+            p.pool = k.pool_fused;
             p.round_half = dtype == YOLO_DTYPE_F16;
             p.out_img_stride = k.out.img_stride;
             p.total = (long long)batch * k.in.H * k.in.W;
@@ -438,7 +439,8 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         out->flops = 2.0 * k.out.H * k.out.W * k.cout * 27;
         out->bytes = (double)k.in.H * k.in.W * 3 * 4 + elems(k.out) * esz(k.out);
         out->weight_bytes = 28.0 * k.cout * 4;
-        snprintf(out->name, sizeof out->name, "conv_first<%s,%d>", t, k.cout);
+        snprintf(out->name, sizeof out->name, k.pool_fused ? "conv_first_pool<%s,%d>" : "conv_first<%s,%d>", t, k.cout);
+        if (k.pool_fused) { out->out_h = k.in.H; out->out_w = k.in.W; out->flops = 2.0 * k.in.H * k.in.W * k.cout * 27; }
         if (k.stem == 1) {          // no launch of its own: accounted for in the conv_stem kernel that follows
             out->flops = 0; out->bytes = 0; out->weight_bytes = 0;
             snprintf(out->name, sizeof out->name, "conv_first<fused into conv_stem>");

@@ -411,6 +411,22 @@ struct Planner {
             case YOLO_OP_MAXPOOL: {
                 int s = resolve(d.src[0]);
                 if (!L[s].materialised) return fail(std::string(nm) + "source not materialised");
+                // Darknet-19 / tiny-YOLO: the 2x2/2 pool right behind the first conv is taken inside the first-layer kernel
+                // (the full-resolution tensor is never written) when nobody else reads that tensor
+                if (i == 2 && s == 1 && first_direct && !net->kernels.empty() && net->kernels.back().kind == K_FIRST && sole(1, 2) &&
+                    !net->opt.keep_all && d.stride == 2 && L[1].H % 2 == 0 && L[1].W % 2 == 0 && !getenv("YOLO_NO_FIRST_POOL")) {
+                    View pv = out_view_for(i);
+                    if (!pv.f32 && pv.ld % epc == 0 && (pv.base + pv.coff) % epc == 0 && pv.img_stride % epc == 0) {
+                        Kernel &f = net->kernels.back();
+                        f.pool_fused = 1;
+                        f.out = pv;
+                        f.layer = i;
+                        f.note += " + fused 2x2/2 max-pool (layer 2)";
+                        L[i].view = pv; L[i].materialised = true;
+                        L[1].materialised = false;
+                        break;
+                    }
+                }
                 Kernel k;
                 k.kind = K_POOL; k.layer = i; k.in = L[s].view; k.pool_stride = d.stride;
                 if (k.in.f32) return fail(std::string(nm) + "maxpool cannot read a float32 head tensor");

@@ -116,6 +116,9 @@ struct FirstParams {           // first layer: 3x3/1 conv on the float32 NHWC3 i
     long long out_img_stride;
     long long total;           // B*H*W output pixels (< 2^31)
     FastDiv dW, dH, dHW;       // set by launch_first
+    int pool;                  // 1: the 2x2/2 max-pool behind the conv is fused; `out` is the POOLED tensor [B,H/2,W/2,Cout]
+    int xblocks;               // pool: 128-wide x blocks per row (set by launch_first)
+    FastDiv dXB, dHp;
 };
 
 struct StemParams {            // stem.hip: fused conv 3x3/1 3->32 + conv 3x3/2 32->64 (both BN + leaky), fp16 nets
@@ -226,6 +229,7 @@ struct Kernel {
     int ksize = 0, stride = 0, cout = 0, cin = 0, cin_s = 0, leaky = 0, outmode = 0, has_res = 0;
     int cfg = 0, perchunk = 0, cpt = 0, ktiles = 0;
     int tile = -1;             // conv_dma tile id chosen by yolo_net_autotune (-1: heuristic)
+    int pool_fused = 0;        // K_FIRST: the max-pool layer behind it is taken in the same kernel
     int stem = 0;              // 1: first-layer kernel fused away into the next conv; 2: this conv runs as stem.hip with it;
                                // 3: this 1x1 conv is computed by the stem kernel in front of it (no launch)
     size_t w_off = 0, b_off = 0, w_bytes = 0;   // inside the device weight blob

@@ -195,6 +195,23 @@ def test_errors_are_reported():
         eng.load_weights(np.zeros(5, np.float32))
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("shape,cout", [((2, 32, 40), 32), ((1, 18, 300), 16), ((3, 6, 130), 32), ((2, 9, 20), 16)])
+def test_first_conv_with_fused_pool(shape, cout, dtype):
+    """Darknet-19 / tiny-YOLO head of the graph: first 3x3/1 conv (32 or 16 filters) + the 2x2/2 max-pool behind it in
+    one kernel (x blocks of 128 with a tail, several images); an odd height keeps the two-kernel path"""
+    B, H, W = shape
+    g = new_graph(H, W, 3)
+    g.append(PL.conv2d_bn_act(g[-1].out, cout, 3, 1))
+    g.append(PL.max_pool2d(g[-1].out, 2, stride=2))
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))
+    g.append(PL.max_pool2d(g[-1].out, 2, stride=1))
+    x = synth.synthetic_input(B, H, W, 3, seed=41)
+    eng = check_graph(g, x, dtype, seed=9)
+    names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
+    assert ("conv_first_pool" in names) == (H % 2 == 0 and W % 2 == 0), names
+
+
 @pytest.mark.parametrize("shape", [(3, 40, 56), (2, 64, 64), (1, 18, 34), (2, 21, 30)])
 def test_fused_stem(shape):
     """Darknet-53 stem (stem.hip): first 3x3/1 3->32 conv and the 3x3/2 32->64 conv behind it as one kernel; partial
