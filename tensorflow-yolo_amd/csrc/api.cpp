@@ -183,6 +183,15 @@ int make_conv_params(yolo_net *net, const Kernel &k, const Ptrs &P, int batch, C
     const int oepc = p.out_f32 ? 4 : epc;
     p.vec_out = (k.cout % ch == 0) && (k.out.ld % oepc == 0) && ((k.out.base + k.out.coff) % oepc == 0) &&
                 (k.out.img_stride % oepc == 0) && ((uintptr_t)P.buf_base(k.out.buf) % 16 == 0);
+    if (k.head && net->obj_bytes && net->head.n_classes > 0 && !p.vec_out && p.out_f32 && k.outmode == OUT_NORMAL && !k.has_res) {
+        const int width = 5 + net->head.n_classes;
+        const long long base = k.out.base + k.out.coff;
+        const size_t rows = net->out_count / (size_t)width;
+        if (k.out.ld % width == 0 && base % width == 0 && rows * width == net->out_count && (size_t)batch * rows * 4 <= net->obj_bytes) {
+            p.obj_out = reinterpret_cast<float *>(net->dev_ws + net->obj_off);
+            p.obj_width = width; p.obj_rows = (int)rows; p.obj_row0 = (int)(base / width); p.obj_na = k.out.ld / width;
+        }
+    }
     if (k.has_res) {
         p.res = P.view_ptr(k.in2);
         p.res_ld = k.in2.ld;
@@ -213,6 +222,7 @@ int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, h
     Ptrs P{net, in_dev, out_dev};
     const int dtype = net->opt.dtype;
     const int epc = net->epc;
+    long long obj_rows_written = 0;          // rows of the compact objectness array the head convs of this pass fill
     for (size_t ki = 0; ki < net->kernels.size(); ++ki) {
         const Kernel &k = net->kernels[ki];
         hipError_t e = hipSuccess;
@@ -258,6 +268,7 @@ int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, h
             ConvParams p;
             int rc = make_conv_params(net, k, P, batch, p);
             if (rc) return rc;
+            if (k.head && p.obj_out) obj_rows_written += (long long)p.Ho * p.Wo * p.obj_na;
             e = launch_conv_any(net, k, p, k.tile, s);
             break;
         }
@@ -313,6 +324,8 @@ int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, h
         }
         if (ev && hipEventRecord(ev[2 * ki + 1], s) != hipSuccess) return fail(YOLO_ERR_HIP, "hipEventRecord failed");
     }
+    net->obj_valid = net->obj_bytes > 0 && net->head.n_classes > 0 &&
+                     obj_rows_written == (long long)(net->out_count / (size_t)(5 + net->head.n_classes));
     return YOLO_OK;
 }
 
@@ -339,11 +352,12 @@ void fill_decode(const yolo_head_desc &h, DecodeParams &dp) {
 
 int run_decode_nms(const yolo_head_desc &h, const float *logits, int batch, double thr, double iou, int mode, int cap,
                    int max_boxes, unsigned char *cand, int *cand_count, yolo_box *boxes, int32_t *counts, int32_t *status,
-                   int32_t *keep_idx, hipStream_t s, unsigned char *nms_scratch = nullptr) {
+                   int32_t *keep_idx, hipStream_t s, unsigned char *nms_scratch = nullptr, const float *obj = nullptr) {
     DecodeParams dp;
     memset(&dp, 0, sizeof dp);
     fill_decode(h, dp);
     dp.logits = logits;
+    dp.obj = obj;
     dp.threshold = (float)thr;      // `p < threshold` compares in float32 under NumPy 2 (weak Python float)
     dp.cap = cap;
     dp.cand = cand;
@@ -506,7 +520,8 @@ int yolo_net_detect(yolo_net *net, const float *in_dev, int batch, double thresh
     if (rc) return rc;
     return run_decode_nms(net->head, logits, batch, threshold, iou_threshold, nms_mode, net->opt.cand_capacity,
                           net->opt.max_boxes, net->dev_ws + net->cand_off, reinterpret_cast<int *>(net->dev_ws + net->count_off),
-                          boxes_dev, counts_dev, status_dev, nullptr, s, net->dev_ws + net->nms_off);
+                          boxes_dev, counts_dev, status_dev, nullptr, s, net->dev_ws + net->nms_off,
+                          net->obj_valid ? reinterpret_cast<const float *>(net->dev_ws + net->obj_off) : nullptr);
 }
 
 int yolo_net_read_layer(yolo_net *net, int layer, int batch, float *host_out, size_t n) {

@@ -214,12 +214,23 @@ __device__ __forceinline__ void conv_epilogue_f32_staged(const ConvParams &p, fl
                 }
     }
     float *op = reinterpret_cast<float *>(p.out);
+    // objectness logits (channel a * (5+C) + 4 of anchor a) also go to a compact [B][rows] array for the decode kernel,
+    // which otherwise touches one 64-byte sector per row to read 4 bytes of it
+    constexpr int NH = (4 * CH + 63) / 64;
+    int obj_a[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const int cg = cbase_wave + lane + 64 * h;
+        const int a = p.obj_out ? cg / p.obj_width : 0;
+        obj_a[h] = (p.obj_out && lane + 64 * h < 4 * CH && cg < p.Cout && cg - a * p.obj_width == 4) ? a : -1;
+    }
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
         int n, rem, oy, ox;
         const bool ok = conv_decode_pixel<PADQ>(p, m_wave + b * 16 + fr, n, rem, oy, ox);
         const long long off = (long long)n * p.out_img_stride + (long long)rem * p.out_ld;
         const int off_lo = (int)(off & 0xffffffffLL), off_hi = (int)(off >> 32), oki = ok ? 1 : 0;
+        const int orow = n * p.obj_rows + p.obj_row0 + rem * p.obj_na;
 #pragma unroll
         for (int a = 0; a < TM; ++a) *reinterpret_cast<float4v *>(slab + fr * PITCH + fq * CH + 4 * a) = acc[a][b];
         __builtin_amdgcn_wave_barrier();        // LDS executes a wave's instructions in order: the reads below see these writes
@@ -227,10 +238,15 @@ __device__ __forceinline__ void conv_epilogue_f32_staged(const ConvParams &p, fl
         for (int pp = 0; pp < 16; ++pp) {
             if (!__builtin_amdgcn_readlane(oki, pp)) continue;         // wave-uniform
             const long long po = ((long long)__builtin_amdgcn_readlane(off_hi, pp) << 32) | (unsigned)__builtin_amdgcn_readlane(off_lo, pp);
+            const int orow_pp = __builtin_amdgcn_readlane(orow, pp);
 #pragma unroll
-            for (int h = 0; h < (4 * CH + 63) / 64; ++h) {
+            for (int h = 0; h < NH; ++h) {
                 const int c = lane + 64 * h;
-                if (c < 4 * CH && cbase_wave + c < p.Cout) op[po + cbase_wave + c] = slab[pp * PITCH + c];
+                if (c < 4 * CH && cbase_wave + c < p.Cout) {
+                    const float v = slab[pp * PITCH + c];
+                    op[po + cbase_wave + c] = v;
+                    if (obj_a[h] >= 0) p.obj_out[orow_pp + obj_a[h]] = v;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();

@@ -18,22 +18,45 @@ __device__ __forceinline__ float sigmoid_f32(float x) { return 1.f / (1.f + expf
 __global__ void __launch_bounds__(256) decode_kernel(const DecodeParams p) {
     const int width = 5 + p.n_classes;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < p.total_rows; row += stride) {
+    const int lane = threadIdx.x & 63;
+    // (whole waves stay in the loop together: the v3 path uses wave-wide shuffles)
+    for (long long row0 = (long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63); row0 < p.total_rows; row0 += stride) {
+        const bool live = row0 + lane < p.total_rows;
+        const long long row = live ? row0 + lane : p.total_rows - 1;
         const int b = (int)(row / p.rows);
         const int r = (int)(row - (long long)b * p.rows);
         const float *t = p.logits + row * width;
-        const float po = sigmoid_f32(t[4]);
+        const float po = sigmoid_f32(p.obj ? p.obj[row] : t[4]);      // compact copy written by the head convs: coalesced
         float prob;
         int cls = 0;
         if (p.version == 3) {
             prob = po;                                  // v3.py:123 p = prob_obj
-            if (prob < p.threshold) continue;           // v3.py:124 (p == thr is kept)
-            float best = sigmoid_f32(t[5]);
-            for (int k = 1; k < p.n_classes; ++k) {     // v3.py:120-121 argmax of sigmoid(cls): first max wins
-                const float s = sigmoid_f32(t[5 + k]);
-                if (s > best) { best = s; cls = k; }
+            // v3.py:120-121 argmax of sigmoid(cls), first max wins.  The few rows of a wave that pass the threshold
+            // (v3.py:124, p == thr is kept) are served one after the other by ALL 64 lanes (a class or two per lane +
+            // a butterfly argmax that prefers the lower index on ties) instead of 80 serial sigmoids on one lane.
+            unsigned long long todo = __ballot(live && !(prob < p.threshold));
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const long long srow = ((long long)__shfl((int)(row >> 32), src) << 32) | (unsigned)__shfl((int)(row & 0xffffffffLL), src);
+                const float *ts = p.logits + srow * width + 5;
+                float s0 = -1.f;
+                int k0 = 0x7fffffff;
+                for (int k = lane; k < p.n_classes; k += 64) {
+                    const float sk = sigmoid_f32(ts[k]);
+                    if (sk > s0) { s0 = sk; k0 = k; }  // ascending k per lane: strict > keeps the first maximum
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float so = __shfl_xor(s0, off);
+                    const int ko = __shfl_xor(k0, off);
+                    if (so > s0 || (so == s0 && ko < k0)) { s0 = so; k0 = ko; }
+                }
+                if (lane == src) cls = k0;
             }
+            if (!live || prob < p.threshold) continue;
         } else {
+            if (!live) continue;
             if (po < p.threshold) continue;             // p = po * pc <= po: cheap early out, same result
             float mx = t[5];
             for (int k = 1; k < p.n_classes; ++k) mx = fmaxf(mx, t[5 + k]);
@@ -84,7 +107,7 @@ __global__ void __launch_bounds__(1024) nms_kernel(const NmsParams p) {
     unsigned char *lds = GLOBAL ? p.scratch + (size_t)blockIdx.x * p.scratch_stride : nms_dyn_lds;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    const int nthr = blockDim.x;
+    int nthr = blockDim.x;
     int count = p.cand_count[b];
     int status = 0;
     if (count > p.cap) { count = p.cap; status = 1; }
@@ -93,6 +116,9 @@ __global__ void __launch_bounds__(1024) nms_kernel(const NmsParams p) {
         if (tid == 0) { p.counts[b] = 0; p.status[b] = status; }
         return;
     }
+    // few candidates are the usual case: surplus waves leave before the first barrier (terminated waves do not take part)
+    if (n <= 256) nthr = 256;
+    if (tid >= nthr) return;
     int n2 = 2;
     while (n2 < n) n2 <<= 1;
     int cap2 = 2;

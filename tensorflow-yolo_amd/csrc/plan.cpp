@@ -369,6 +369,7 @@ struct Planner {
                 }
                 k.layer = key;
                 if (has_head[i]) {
+                    k.head = 1;
                     k.out = head_target[i];
                     k.note += " -> head logits (float32, reference layout)";
                 } else {
@@ -600,6 +601,9 @@ int plan_network(yolo_net *net, const yolo_layer_desc *layers, int n, std::strin
     off += roundup_sz(sizeof(int) * (size_t)net->opt.max_batch, 4096);
     net->nms_off = off;
     off += roundup_sz(nms_scratch_bytes(net->opt.cand_capacity) * (size_t)net->opt.max_batch, 4096);
+    net->obj_off = off;
+    net->obj_bytes = net->head.n_classes > 0 ? (size_t)net->opt.max_batch * (net->out_count / (size_t)(5 + net->head.n_classes)) * 4 : 0;
+    off += roundup_sz(net->obj_bytes, 4096);
     net->workspace_bytes = off;
     return YOLO_OK;
 }

@@ -88,6 +88,8 @@ struct ConvParams {
     int n_tiles_n, n_blocks;
     int dbg;                   // experiment flags (YOLO_CONV_DBG): 1 skip steady-state DMA, 2 skip MFMA phase
     int qW, qHW, Mq;           // conv_tap.hip: padded-linear pixel grid, row stride W+1, image stride (H+1)(W+1), total
+    float *obj_out;            // head convs (staged float32 epilogue): compact objectness logits [B][obj_rows] or null
+    int obj_width, obj_rows, obj_row0, obj_na;     // 5 + classes; rows per image; first row of this scale; anchors per cell
     unsigned long long *trace; // conv_tap.hip: per-block phase timestamps (YOLO_CONV_TRACE experiment) or null
     FastDiv dHoWo, dWo, dqHW, dqW, dtiles_n, dtpt;   // set by the launchers (conv_set_divisors); dtpt: K stages per tap
 };
@@ -164,6 +166,7 @@ struct DecodeScale {
 
 struct DecodeParams {
     const float *logits;       // [B, rows, 5+C]
+    const float *obj;          // optional compact copy of logits[..., 4] ([B, rows]): one coalesced read per row
     int version, n_classes, rows, n_scales;
     DecodeScale sc[YOLO_MAX_SCALES];
     float threshold;
@@ -229,6 +232,7 @@ struct Kernel {
     int ksize = 0, stride = 0, cout = 0, cin = 0, cin_s = 0, leaky = 0, outmode = 0, has_res = 0;
     int cfg = 0, perchunk = 0, cpt = 0, ktiles = 0;
     int tile = -1;             // conv_dma tile id chosen by yolo_net_autotune (-1: heuristic)
+    int head = 0;              // conv writes float32 head logits into the reference-layout output
     int pool_fused = 0;        // K_FIRST: the max-pool layer behind it is taken in the same kernel
     int stem = 0;              // 1: first-layer kernel fused away into the next conv; 2: this conv runs as stem.hip with it;
                                // 3: this 1x1 conv is computed by the stem kernel in front of it (no launch)
@@ -261,6 +265,8 @@ struct yolo_net {
     size_t weights_bytes = 0;
     size_t act_bytes = 0;          // activation part of the workspace
     size_t logits_off = 0, cand_off = 0, count_off = 0, nms_off = 0;   // nms_off: global NMS slabs (cand_capacity > 4096)
+    size_t obj_off = 0, obj_bytes = 0;     // compact objectness logits [max_batch][rows] written by the head convs for the decode
+    bool obj_valid = false;                // ... and whether the last forward filled all of it
     size_t workspace_bytes = 0;
     size_t out_count = 0;          // floats per image of the head output
     double flops_per_image = 0;
