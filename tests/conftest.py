@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the C-ABI library is a build product (git-ignored): build it once if a fresh checkout has none yet
+    # (hipcc cross-compiles gfx950 without a GPU; ~15 s).  The product never falls back to anything else.
+    so = os.path.join(ROOT, "tensorflow-yolo_amd", "libyolo_hip.so")
+    if not os.path.exists(so):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
