@@ -17,6 +17,7 @@
  *                           (+ net/base.py:195-209 non_maximum_suppression)
  *   yolo_net_detect         net/yolo.py:83-86 (forward + find_bounding_boxes in one enqueue)
  *   yolo_nms_host           net/base.py:195-209 non_maximum_suppression on a host box list
+ *   yolo_preprocess_resize  net/base.py:115-155 preprocess_image (resize + colour order + /255) on the device
  */
 #ifndef YOLO_HIP_H
 #define YOLO_HIP_H
@@ -175,6 +176,14 @@ int yolo_decode_nms(const yolo_head_desc *head, const float *logits_dev, int bat
                     double iou_threshold, int nms_mode, int cand_capacity, int max_boxes, void *scratch_dev,
                     size_t scratch_bytes, yolo_box *boxes_dev, int32_t *counts_dev, int32_t *status_dev,
                     void *stream);
+
+/* Image preprocessing of the TEST loop, replaces net/base.py:115-155 (cv2.resize INTER_LINEAR stretch to the network
+ * input, optional BGR<->RGB swap, / 255.): src_dev is a decoded uint8 HWC image with 3 channels on the device
+ * (src_row_bytes >= 3*src_w), dst_dev receives float32 [dst_h][dst_w][3] in [0,1].  Bit-exact with OpenCV's published
+ * 8-bit INTER_LINEAR algorithm as restated in oracle/preprocess_ref.py (OpenCV itself is not available: unpinned).
+ * Enqueued on `stream`. */
+int yolo_preprocess_resize(const uint8_t *src_dev, int src_h, int src_w, int src_row_bytes, float *dst_dev, int dst_h, int dst_w,
+                           int swap_rb, void *stream);
 
 /* NMS of a HOST list (x,y,w,h as double, prob float, class int; scan order = index).  Synchronous;
  * allocates its own scratch.  keep_idx receives the indices of survivors in output order. */

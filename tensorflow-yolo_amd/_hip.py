@@ -76,6 +76,7 @@ SIGNATURES = {
     "yolo_decode_nms": (C.c_int, [C.POINTER(HeadDesc), C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int,
                                   C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
+    "yolo_preprocess_resize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "yolo_nms_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int,
                                 C.c_void_p, C.POINTER(C.c_int32)]),
 }

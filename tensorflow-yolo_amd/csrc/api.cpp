@@ -577,6 +577,17 @@ int yolo_decode_nms(const yolo_head_desc *head, const float *logits_dev, int bat
                           boxes_dev, counts_dev, status_dev, nullptr, static_cast<hipStream_t>(stream), slabs);
 }
 
+int yolo_preprocess_resize(const uint8_t *src_dev, int src_h, int src_w, int src_row_bytes, float *dst_dev, int dst_h, int dst_w,
+                           int swap_rb, void *stream) {
+    if (!src_dev || !dst_dev || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0 || src_row_bytes < 3 * src_w)
+        return fail(YOLO_ERR_ARG, "yolo_preprocess_resize: bad argument");
+    ResizeParams p;
+    p.src = src_dev; p.dst = dst_dev;
+    p.src_h = src_h; p.src_w = src_w; p.src_row_bytes = src_row_bytes; p.dst_h = dst_h; p.dst_w = dst_w; p.swap_rb = swap_rb ? 1 : 0;
+    HIP_TRY(launch_resize(p, static_cast<hipStream_t>(stream)));
+    return YOLO_OK;
+}
+
 int yolo_nms_host(const double *xywh, const float *prob, const int32_t *class_idx, int n, double iou_threshold, int nms_mode,
                   int32_t *keep_idx, int32_t *n_keep) {
     if (n < 0 || !n_keep || (n && (!xywh || !prob || !class_idx || !keep_idx))) return fail(YOLO_ERR_ARG, "yolo_nms_host: null argument");

@@ -125,6 +125,56 @@ static inline unsigned grid_for(long long work) {
     return (unsigned)g;
 }
 
+// Image preprocessing of the TEST loop (reference net/base.py:115-155: cv2.resize INTER_LINEAR stretch, BGR->RGB, / 255.):
+// one thread per destination pixel.  8-bit INTER_LINEAR as OpenCV defines it (imgproc/resize.cpp): half-pixel centres,
+// weights rounded to 11-bit fixed point, horizontal pass in int32, vertical pass
+// ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2; then float32(v / 255.) (division in float64 like NumPy).
+__device__ __forceinline__ void resize_coeff(int d, int src, int dst, int &s0, int &s1, int &w0, int &w1) {
+#pragma clang fp contract(off)
+    const double scale = (double)src / (double)dst;
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= src - 1) { f = 0.f; s = src - 1; }
+    w0 = __float2int_rn((1.f - f) * 2048.f);        // cvRound: round half to even
+    w1 = __float2int_rn(f * 2048.f);
+    s0 = s;
+    s1 = s + 1 < src ? s + 1 : src - 1;
+}
+
+__global__ void __launch_bounds__(256) resize_u8_kernel(const ResizeParams p) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)p.dst_h * p.dst_w) return;
+    const int dy = (int)(i / p.dst_w), dx = (int)(i - (long long)dy * p.dst_w);
+    int x0, x1, a0, a1, y0, y1, b0, b1;
+    resize_coeff(dx, p.src_w, p.dst_w, x0, x1, a0, a1);
+    resize_coeff(dy, p.src_h, p.dst_h, y0, y1, b0, b1);
+    const unsigned char *r0 = p.src + (long long)y0 * p.src_row_bytes, *r1 = p.src + (long long)y1 * p.src_row_bytes;
+    const bool same = p.src_h == p.dst_h && p.src_w == p.dst_w;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int cs = p.swap_rb ? 2 - c : c;
+        int v;
+        if (same) {
+            v = r0[x0 * 3 + cs];
+        } else {
+            const int h0 = (int)r0[x0 * 3 + cs] * a0 + (int)r0[x1 * 3 + cs] * a1;
+            const int h1 = (int)r1[x0 * 3 + cs] * a0 + (int)r1[x1 * 3 + cs] * a1;
+            v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        p.dst[i * 3 + c] = (float)((double)v / 255.);
+    }
+}
+
+hipError_t launch_resize(const ResizeParams &p, hipStream_t s) {
+    const long long n = (long long)p.dst_h * p.dst_w;
+    if (n <= 0 || p.src_h <= 0 || p.src_w <= 0 || (n + 255) / 256 > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(resize_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_prep(const PrepParams &p, int dtype, hipStream_t s) {
     if (dtype == YOLO_DTYPE_F16) hipLaunchKernelGGL(prep_kernel<_Float16>, dim3(grid_for(p.pixels)), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(prep_kernel<float>, dim3(grid_for(p.pixels)), dim3(256), 0, s, p);

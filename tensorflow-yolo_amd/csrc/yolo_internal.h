@@ -142,6 +142,12 @@ struct StemParams {            // stem.hip: fused conv 3x3/1 3->32 + conv 3x3/2 
     FastDiv dtx, dty;
 };
 
+struct ResizeParams {          // uint8 HWC3 image -> float32 [dst_h][dst_w][3] in [0,1] (aux.hip: resize_u8_kernel)
+    const unsigned char *src;
+    float *dst;
+    int src_h, src_w, src_row_bytes, dst_h, dst_w, swap_rb;
+};
+
 struct PoolParams {            // net/layers.py:70-81
     const void *in;
     void *out;
@@ -213,6 +219,7 @@ const char *dma_cfg_name(int cfg);
 int dma_num_cfgs();
 int dma_cfg_na(int cfg);
 hipError_t launch_prep(const PrepParams &p, int dtype, hipStream_t s);
+hipError_t launch_resize(const ResizeParams &p, hipStream_t s);
 hipError_t launch_first(const FirstParams &p, int dtype, hipStream_t s);
 hipError_t launch_stem(const StemParams &p, int batch, hipStream_t s);     // stem.hip
 hipError_t launch_pool(const PoolParams &p, int dtype, hipStream_t s);

@@ -107,6 +107,49 @@ def preprocess_image(image_path, new_shape):
     return np.asarray(img, dtype=np.float64) / 255.
 
 
+def decode_image(image_path):
+    """JPEG/PNG decode to RGB uint8 [H,W,3] on the host (Pillow; the reference uses cv2.imread, net/base.py:117)."""
+    from PIL import Image
+    try:
+        img = Image.open(image_path)
+        img.load()
+    except Exception:
+        print("Failed to read {}".format(image_path))
+        return None
+    return np.array(img.convert("RGB"), dtype=np.uint8)         # a writable, contiguous copy
+
+
+def preprocess_image_gpu(image_path, new_shape, device=None, stream=None):
+    """preprocess_image with the resize / colour order / /255 on the device (yolo_preprocess_resize): OpenCV's 8-bit
+    INTER_LINEAR arithmetic (what the reference's cv2.resize computes, restated in oracle/preprocess_ref.py) instead of
+    Pillow's resampler.  Returns a float32 CUDA tensor [h, w, 3] or None when the file cannot be read."""
+    import torch
+    rgb = decode_image(image_path)
+    if rgb is None:
+        return None
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    src = torch.from_numpy(rgb).to(dev)
+    dst = torch.empty((int(new_shape[0]), int(new_shape[1]), 3), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+    _hip.check(_hip.lib().yolo_preprocess_resize(src.data_ptr(), rgb.shape[0], rgb.shape[1], rgb.shape[1] * 3, dst.data_ptr(),
+                                                 int(new_shape[0]), int(new_shape[1]), 0, st), "yolo_preprocess_resize")
+    return dst
+
+
+def generate_test_batch_gpu(img_paths, batch_size, input_shape):
+    """generate_test_batch with device-side preprocessing: yields ([B,h,w,3] float32 CUDA tensor, paths)."""
+    import torch
+    for start in range(0, len(img_paths), batch_size):
+        chunk = img_paths[start:start + batch_size]
+        images = []
+        for p in chunk:
+            image = preprocess_image_gpu(p, input_shape)
+            if image is None:
+                raise IOError("cannot read image {}".format(p))
+            images.append(image)
+        yield torch.stack(images, dim=0), chunk
+
+
 def generate_test_batch(img_paths, batch_size, input_shape):
     """Yields ([B,h,w,c] float array, paths); the last batch may be short (reference net/base.py:158-168)."""
     for start in range(0, len(img_paths), batch_size):

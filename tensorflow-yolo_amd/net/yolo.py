@@ -103,7 +103,10 @@ class Yolo(object):
         type(self).load_weights(self.net, pretrained_weights_path)
         print("Pre-trained weights loaded.")
 
-        for x_batch, paths in base.generate_test_batch(image_paths, batch_size, input_shape):
+        # resize / colour order / /255 run on the device with OpenCV's INTER_LINEAR arithmetic (base.preprocess_image_gpu);
+        # `preprocess = pillow` (new optional key) keeps the host-side Pillow resampler
+        batches = base.generate_test_batch if str(params.get("preprocess", "gpu")).lower() == "pillow" else base.generate_test_batch_gpu
+        for x_batch, paths in batches(image_paths, batch_size, input_shape):
             net_boxes = self.predict(x_batch, threshold, iou_threshold, nms_mode)
             for boxes, path in zip(net_boxes, paths):
                 new_img = base.draw_boxes(path, boxes, class_names)

@@ -66,3 +66,26 @@ def test_engineered_semantics():
     assert [int(c) for c in g["equal_prob_keeps_scan_order"][:, 4]] == [3, 4, 6]   # stable order, 5 suppressed by 3
     assert len(g["zero_area_union_floor"]) == 2             # 0/1e-8 = 0 < thr
     assert len(g["empty"]) == 0
+
+
+def test_preprocess_restatement_properties():
+    """oracle/preprocess_ref.py (OpenCV 8-bit INTER_LINEAR, unpinned: no cv2 here): identity at equal size, constants
+    stay constant, corners of an up-scale equal the source corners, a 2x2 -> 1x1 reduction is the rounded mean, and
+    the result is within one grey level of a float64 bilinear evaluation at half-pixel centres"""
+    from oracle import preprocess_ref as P
+    rng = np.random.RandomState(1)
+    im = rng.randint(0, 256, size=(9, 13, 3)).astype(np.uint8)
+    assert np.array_equal(P.resize_linear_u8(im, 9, 13), im)
+    assert (P.resize_linear_u8(np.full((5, 6, 3), 77, np.uint8), 11, 3) == 77).all()
+    up = P.resize_linear_u8(im, 27, 39)
+    assert (up[0, 0] == im[0, 0]).all() and (up[-1, -1] == im[-1, -1]).all()
+    q = np.array([[[10], [20]], [[30], [41]]], np.uint8).repeat(3, axis=2)
+    assert int(P.resize_linear_u8(q, 1, 1)[0, 0, 0]) in (25, 26)
+    H, W, dh, dw = 9, 13, 20, 7
+    ys = np.clip((np.arange(dh) + 0.5) * H / dh - 0.5, 0, H - 1); xs = np.clip((np.arange(dw) + 0.5) * W / dw - 0.5, 0, W - 1)
+    y0 = np.floor(ys).astype(int); x0 = np.floor(xs).astype(int); y1 = np.minimum(y0 + 1, H - 1); x1 = np.minimum(x0 + 1, W - 1)
+    fy = (ys - y0)[:, None, None]; fx = (xs - x0)[None, :, None]
+    f = im.astype(np.float64)
+    ref = (f[y0][:, x0] * (1 - fx) + f[y0][:, x1] * fx) * (1 - fy) + (f[y1][:, x0] * (1 - fx) + f[y1][:, x1] * fx) * fy
+    assert np.abs(P.resize_linear_u8(im, dh, dw).astype(np.float64) - ref).max() <= 1.0
+    assert P.preprocess(im, (4, 4)).dtype == np.float32
