@@ -41,7 +41,7 @@ VOC_TINY = [1.08, 1.19, 3.42, 4.41, 6.63, 11.38, 9.42, 5.11, 16.62, 10.52]
 COCO_V3 = [10, 13, 16, 30, 33, 23, 30, 61, 62, 45, 59, 119, 116, 90, 156, 198, 373, 326]
 
 
-def make_model(kind, size, batch, dtype, seed=0):
+def make_model(kind, size, batch, dtype, seed=0, streams=0):
     from tensorflow_yolo_amd import YoloV2, YoloV2Tiny, YoloV3
     from tensorflow_yolo_amd.net import synth
     cls, anchors, ncls = {"v3": (YoloV3, COCO_V3, 80), "v2": (YoloV2, COCO_V2, 80), "v2-tiny": (YoloV2Tiny, VOC_TINY, 20)}[kind]
@@ -50,7 +50,7 @@ def make_model(kind, size, batch, dtype, seed=0):
     net = cls.create_network(np.reshape(anchors, [-1, 2]), names, False, input_shape=(size, size, 3))
     hg, frac = synth.HEAD_DEFAULTS[kind]
     w = synth.darknet_stream(net, seed=seed, num_classes=ncls, head_gain=hg, obj_bias=0.0)
-    model.build(anchors, names, (size, size, 3), dtype=dtype, max_batch=batch, weights=w)
+    model.build(anchors, names, (size, size, 3), dtype=dtype, max_batch=batch, weights=w, streams=streams)
     # data-dependent objectness prior (uses the product's own forward): a realistic handful of candidates
     w = synth.calibrate_model(model, synth.synthetic_input(min(batch, 2), size, size, 3, seed=999), frac)
     return model, w, anchors, ncls
@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--workload", default="v3-608-b32-fp16", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--autotune", action="store_true", help="time every conv tile per layer on the device first (default: built-in rules)")
+    ap.add_argument("--streams", type=int, default=0, help="run every batch as this many independent parts on as many HIP streams "
+                    "(overlaps the kernels' tails; the per-kernel roofline figures then describe one part's launches run alone)")
     ap.add_argument("--threshold", type=float, default=0.5)
     ap.add_argument("--iou-threshold", type=float, default=0.6)
     ap.add_argument("--dump-kernels", default=None, help="write the per-kernel timing table (JSON) here")
@@ -130,7 +132,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     kind, size, batch, dtype = WORKLOADS[args.workload]
-    model, w, anchors, ncls = make_model(kind, size, batch, dtype)
+    model, w, anchors, ncls = make_model(kind, size, batch, dtype, streams=args.streams)
     eng = model.net.engine
     from tensorflow_yolo_amd.net import synth
     # two different resident input batches, alternated, so no step re-reads the previous step's input
@@ -219,7 +221,7 @@ def main():
             "vs_baseline": None, "dtype": "f16" if dtype == "fp16" else "f32", "data": "synthetic",
             "config": {"workload": args.workload, "model": kind, "input": [size, size, 3], "batch_per_gpu": batch,
                        "global_batch": batch * world, "weights": "seeded synthetic Darknet stream (random-init)",
-                       "threshold": args.threshold, "iou_threshold": args.iou_threshold,
+                       "threshold": args.threshold, "iou_threshold": args.iou_threshold, "streams": max(1, args.streams),
                        "sharding": "images over ranks; all-gather of box records only" if world > 1 else "single GPU",
                        "boxes_per_image_last_step": round(float(nboxes.mean()), 1),
                        "forward_gflop_per_image": round(eng.flops_per_image / 1e9, 3)},

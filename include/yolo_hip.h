@@ -85,7 +85,10 @@ typedef struct yolo_net_options {
     int32_t cand_capacity;  /* candidates per image the decode stage can hold (0 -> 4096; up to
                              * 4096 sort + NMS run in LDS, up to 65536 on global-memory slabs)  */
     int32_t max_boxes;      /* records per image written by detect / decode_nms (0 -> 256)     */
-    int32_t reserved[3];
+    int32_t streams;        /* 0/1: one pass on the caller's stream; 2..4: the batch runs as that many independent
+                             * parts on the caller's + internal streams (overlaps the kernels' tails; the
+                             * environment variable YOLO_STREAMS sets the default when this is 0)          */
+    int32_t reserved[2];
 } yolo_net_options;
 
 /* Result record; field names follow net/base.py:257-272 BoundingBox. */

@@ -57,7 +57,13 @@ int yolo_net_create(const yolo_layer_desc *layers, int n_layers, const yolo_net_
     return YOLO_OK;
 }
 
-void yolo_net_destroy(yolo_net *net) { delete net; }
+void yolo_net_destroy(yolo_net *net) {
+    if (!net) return;
+    if (net->e_fork) (void)hipEventDestroy(net->e_fork);
+    for (hipEvent_t e : net->e_join) (void)hipEventDestroy(e);
+    for (hipStream_t st : net->side) (void)hipStreamDestroy(st);
+    delete net;
+}
 
 size_t yolo_net_weight_count(const yolo_net *net) { return net ? net->weight_count : 0; }
 size_t yolo_net_weights_bytes(const yolo_net *net) { return net ? net->weights_bytes : 0; }
@@ -134,12 +140,14 @@ namespace {
 
 struct Ptrs {
     yolo_net *net;
-    const float *in;
-    float *out;
+    const float *in;            // already advanced to image `img0` by the caller
+    float *out;                 // ditto
+    int img0 = 0;               // first image of this pass in the batch (two-stream halves: compact per-image arrays)
+    int arena = 0;              // activation arena of this pass
     unsigned char *buf_base(int b) const {
         if (b == BUF_USER_IN) return reinterpret_cast<unsigned char *>(const_cast<float *>(in));
         if (b == BUF_USER_OUT) return reinterpret_cast<unsigned char *>(out);
-        return net->dev_ws + net->buffers[b].offset;
+        return net->dev_ws + (size_t)arena * net->arena_bytes + net->buffers[b].offset;
     }
     int esz(const View &v) const { return v.f32 ? 4 : net->esize; }
     // element pointer of channel 0 of pixel 0 of image 0 of the view
@@ -188,7 +196,7 @@ int make_conv_params(yolo_net *net, const Kernel &k, const Ptrs &P, int batch, C
         const long long base = k.out.base + k.out.coff;
         const size_t rows = net->out_count / (size_t)width;
         if (k.out.ld % width == 0 && base % width == 0 && rows * width == net->out_count && (size_t)batch * rows * 4 <= net->obj_bytes) {
-            p.obj_out = reinterpret_cast<float *>(net->dev_ws + net->obj_off);
+            p.obj_out = reinterpret_cast<float *>(net->dev_ws + net->obj_off) + (size_t)P.img0 * rows;
             p.obj_width = width; p.obj_rows = (int)rows; p.obj_row0 = (int)(base / width); p.obj_na = k.out.ld / width;
         }
     }
@@ -218,8 +226,9 @@ hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParam
     return tile > 0 ? launch_conv_dma(p, tile, s) : launch_conv(p, net->opt.dtype, k.cfg, k.perchunk != 0, s);
 }
 
-int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, hipStream_t s, hipEvent_t *ev = nullptr) {
-    Ptrs P{net, in_dev, out_dev};
+int run_forward_pass(yolo_net *net, const float *in_dev, int batch, float *out_dev, hipStream_t s, hipEvent_t *ev, int img0, int arena,
+                     long long *obj_rows_out) {
+    Ptrs P{net, in_dev, out_dev, img0, arena};
     const int dtype = net->opt.dtype;
     const int epc = net->epc;
     long long obj_rows_written = 0;          // rows of the compact objectness array the head convs of this pass fill
@@ -261,7 +270,7 @@ int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, h
                     p.out3 = P.view_ptr(t.out);
                     p.out3_ld = t.out.ld; p.out3_img_stride = t.out.img_stride;
                 }
-                e = launch_stem(p, batch, s);
+                e = launch_stem(p, batch, s, net->halves ? 512 / net->arenas : 512);
                 break;
             }
             if (k.stem == 3) break;     // computed by the stem kernel
@@ -324,8 +333,59 @@ int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, h
         }
         if (ev && hipEventRecord(ev[2 * ki + 1], s) != hipSuccess) return fail(YOLO_ERR_HIP, "hipEventRecord failed");
     }
-    net->obj_valid = net->obj_bytes > 0 && net->head.n_classes > 0 &&
-                     obj_rows_written == (long long)(net->out_count / (size_t)(5 + net->head.n_classes));
+    *obj_rows_out = obj_rows_written;
+    return YOLO_OK;
+}
+
+// One forward pass; with YOLO_STREAMS=N (N = 2..4) the batch goes out as N parts on N streams (the caller's and internal
+// ones, fork/join by events): images are independent, so the ragged tail + cold start of every kernel of one part overlaps
+// the bulk of the other parts' kernels instead of leaving CUs idle at each of the ~73 kernel boundaries.  Every part has
+// its own activation arena (plan.cpp: allocate).
+int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, hipStream_t s, hipEvent_t *ev = nullptr) {
+    const long long rows = net->head.n_classes > 0 ? (long long)(net->out_count / (size_t)(5 + net->head.n_classes)) : -1;
+    const int parts = net->arenas;
+    const int per = (net->opt.max_batch + parts - 1) / parts;       // images an arena holds
+    if (parts >= 2 && batch > per) {
+        if (ev) return fail(YOLO_ERR_STATE, "per-kernel events need the parts timed one by one (yolo_net_forward_timed)");
+        if (net->side.empty()) {
+            net->side.resize(parts - 1);
+            net->e_join.resize(parts - 1);
+            for (int i = 0; i < parts - 1; ++i)
+                if (hipStreamCreateWithFlags(&net->side[i], hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&net->e_join[i], hipEventDisableTiming) != hipSuccess)
+                    return fail(YOLO_ERR_HIP, "multi-stream forward: stream/event creation failed");
+            if (hipEventCreateWithFlags(&net->e_fork, hipEventDisableTiming) != hipSuccess)
+                return fail(YOLO_ERR_HIP, "multi-stream forward: event creation failed");
+        }
+        const yolo_layer_desc &d0 = net->layers[0].d;
+        const size_t in_img = (size_t)d0.h * d0.w * d0.c;
+        net->halves = true;         // persistent kernels size their grids for a share of the chip
+        HIP_TRY(hipEventRecord(net->e_fork, s));
+        bool all = true;
+        int used = 0;
+        for (int part = 0, img0 = 0; img0 < batch; ++part, img0 += per) {
+            const int nb = batch - img0 < per ? batch - img0 : per;
+            hipStream_t st = part == 0 ? s : net->side[part - 1];
+            if (part > 0) HIP_TRY(hipStreamWaitEvent(st, net->e_fork, 0));
+            long long w = 0;
+            const int rc = run_forward_pass(net, in_dev + (size_t)img0 * in_img, nb, out_dev + (size_t)img0 * net->out_count, st, nullptr,
+                                            img0, part, &w);
+            if (rc) return rc;
+            all = all && w == rows;
+            used = part + 1;
+        }
+        for (int part = 1; part < used; ++part) {
+            HIP_TRY(hipEventRecord(net->e_join[part - 1], net->side[part - 1]));
+            HIP_TRY(hipStreamWaitEvent(s, net->e_join[part - 1], 0));
+        }
+        net->obj_valid = net->obj_bytes > 0 && rows > 0 && all;
+        return YOLO_OK;
+    }
+    net->halves = false;
+    long long w0 = 0;
+    int rc = run_forward_pass(net, in_dev, batch, out_dev, s, ev, 0, 0, &w0);
+    if (rc) return rc;
+    net->obj_valid = net->obj_bytes > 0 && rows > 0 && w0 == rows;
     return YOLO_OK;
 }
 
@@ -395,10 +455,29 @@ int yolo_net_forward_timed(yolo_net *net, const float *in_dev, int batch, float 
     std::vector<hipEvent_t> ev(2 * nk, nullptr);
     for (auto &e : ev)
         if (hipEventCreate(&e) != hipSuccess) return fail(YOLO_ERR_HIP, "hipEventCreate failed");
-    rc = run_forward(net, in_dev, batch, out_dev, s, ev.data());
-    if (rc == YOLO_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(YOLO_ERR_HIP, "hipStreamSynchronize failed");
-    for (size_t k = 0; rc == YOLO_OK && k < nk; ++k)
-        if (hipEventElapsedTime(&ms_host[k], ev[2 * k], ev[2 * k + 1]) != hipSuccess) rc = fail(YOLO_ERR_HIP, "hipEventElapsedTime failed");
+    // with several arenas the parts are timed one after the other on the caller's stream (each kernel alone on the chip)
+    // and their times added per kernel
+    const int parts = net->arenas;
+    const int per = (net->opt.max_batch + parts - 1) / parts;
+    const yolo_layer_desc &d0 = net->layers[0].d;
+    const size_t in_img = (size_t)d0.h * d0.w * d0.c;
+    for (size_t k = 0; k < nk; ++k) ms_host[k] = 0.f;
+    net->halves = false;
+    long long rows_written = 0;
+    for (int part = 0, img0 = 0; rc == YOLO_OK && img0 < batch; ++part, img0 += per) {
+        const int nb = batch - img0 < per ? batch - img0 : per;
+        long long w = 0;
+        rc = run_forward_pass(net, in_dev + (size_t)img0 * in_img, nb, out_dev + (size_t)img0 * net->out_count, s, ev.data(), img0, part, &w);
+        rows_written += w;
+        if (rc == YOLO_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(YOLO_ERR_HIP, "hipStreamSynchronize failed");
+        for (size_t k = 0; rc == YOLO_OK && k < nk; ++k) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, ev[2 * k], ev[2 * k + 1]) != hipSuccess) rc = fail(YOLO_ERR_HIP, "hipEventElapsedTime failed");
+            ms_host[k] += t;
+        }
+    }
+    net->obj_valid = false;     // (the timed pass is not followed by a decode)
+    (void)rows_written;
     for (auto &e : ev) (void)hipEventDestroy(e);
     return rc;
 }
@@ -440,7 +519,7 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         }
         int tile = 0;       // which kernel runs at max_batch (bench.py runs at max_batch)
         if (dma_eligible(net, k))
-            tile = k.tile >= 0 ? k.tile : choose_dma_cfg(net->opt.max_batch * li.H * li.W, k.cout, k.cpt, k.ksize * k.ksize, k.has_res, true, k.stride, k.in.W);
+            tile = k.tile >= 0 ? k.tile : choose_dma_cfg((net->opt.max_batch + net->arenas - 1) / net->arenas * li.H * li.W, k.cout, k.cpt, k.ksize * k.ksize, k.has_res, true, k.stride, k.in.W);
         if (tile > 0) {
             out->variant = 8 + tile;
             snprintf(out->name, sizeof out->name, "conv_igemm_dma<f16,%s>", dma_cfg_name(tile));
@@ -472,6 +551,10 @@ int yolo_net_autotune(yolo_net *net, const float *in_dev, int batch, void *strea
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     float *logits = reinterpret_cast<float *>(net->dev_ws + net->logits_off);
+    {   // every launch of a multi-stream net sees one part of the batch: tune for that size (arena 0)
+        const int per = (net->opt.max_batch + net->arenas - 1) / net->arenas;
+        if (batch > per) batch = per;
+    }
     rc = run_forward(net, in_dev, batch, logits, s);      // real activations in every buffer
     if (rc) return rc;
     Ptrs P{net, in_dev, logits};

@@ -543,7 +543,16 @@ struct Planner {
             }
         }
         const size_t align = 4096;
-        for (Buffer &b : B) b.bytes = roundup_sz((size_t)b.elems_per_image * b.esize * net->opt.max_batch + 256, align);
+        // Multi-stream forward (yolo_net_options.streams / YOLO_STREAMS): the batch runs as independent parts, each in its
+        // own arena planned for its share of the batch -- lifetime-based reuse packs tensors of different per-image size into the same
+        // bytes, so two halves at different layers must not share an arena.  Same total memory.
+        {
+            const int want = net->opt.streams > 0 ? net->opt.streams : (getenv("YOLO_STREAMS") ? atoi(getenv("YOLO_STREAMS")) : 1);
+            net->arenas = (want >= 2 && !net->opt.keep_all) ? (want > 4 ? 4 : want) : 1;
+            if (net->arenas > net->opt.max_batch) net->arenas = net->opt.max_batch;
+        }
+        const int arena_batch = (net->opt.max_batch + net->arenas - 1) / net->arenas;
+        for (Buffer &b : B) b.bytes = roundup_sz((size_t)b.elems_per_image * b.esize * arena_batch + 256, align);
         size_t top = 0;
         if (net->opt.keep_all) {
             for (Buffer &b : B) { b.offset = top; top += b.bytes; }
@@ -570,7 +579,8 @@ struct Planner {
                 placed.push_back(id);
             }
         }
-        net->act_bytes = top;
+        net->arena_bytes = roundup_sz(top, align);
+        net->act_bytes = net->arena_bytes * net->arenas;
     }
 };
 

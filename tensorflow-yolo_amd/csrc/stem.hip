@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
     }
 }
 
-hipError_t launch_stem(const StemParams &p0, int batch, hipStream_t s) {
+hipError_t launch_stem(const StemParams &p0, int batch, hipStream_t s, int max_grid) {
     StemParams p = p0;
     if ((p.H & 1) || (p.W & 1) || p.Ho != p.H / 2 || p.Wo != p.W / 2) return hipErrorInvalidValue;
     p.tiles_x = (p.Wo + TX - 1) / TX;
@@ -273,7 +273,7 @@ hipError_t launch_stem(const StemParams &p0, int batch, hipStream_t s) {
     if (tiles <= 0 || tiles > 0x7fffffffLL) return hipErrorInvalidValue;
     p.n_tiles = (int)tiles;
     // persistent workgroups: two per CU (78 KB of LDS each), every one walks tiles blockIdx, blockIdx + grid, ...
-    const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);
+    const unsigned grid = (unsigned)(tiles < max_grid ? tiles : max_grid);
     hipLaunchKernelGGL(stem_v3_kernel, dim3(grid), dim3(512), 0, s, p);
     return hipGetLastError();
 }

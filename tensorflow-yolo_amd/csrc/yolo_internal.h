@@ -221,7 +221,7 @@ int dma_cfg_na(int cfg);
 hipError_t launch_prep(const PrepParams &p, int dtype, hipStream_t s);
 hipError_t launch_resize(const ResizeParams &p, hipStream_t s);
 hipError_t launch_first(const FirstParams &p, int dtype, hipStream_t s);
-hipError_t launch_stem(const StemParams &p, int batch, hipStream_t s);     // stem.hip
+hipError_t launch_stem(const StemParams &p, int batch, hipStream_t s, int max_grid = 512);     // stem.hip
 hipError_t launch_pool(const PoolParams &p, int dtype, hipStream_t s);
 hipError_t launch_eltwise(const EltParams &p, int dtype, hipStream_t s);
 hipError_t launch_decode(const DecodeParams &p, int batch, hipStream_t s);
@@ -274,6 +274,12 @@ struct yolo_net {
     size_t logits_off = 0, cand_off = 0, count_off = 0, nms_off = 0;   // nms_off: global NMS slabs (cand_capacity > 4096)
     size_t obj_off = 0, obj_bytes = 0;     // compact objectness logits [max_batch][rows] written by the head convs for the decode
     bool obj_valid = false;                // ... and whether the last forward filled all of it
+    std::vector<hipStream_t> side;         // multi-stream forward (YOLO_STREAMS=N): internal streams + fork/join events
+    hipEvent_t e_fork = nullptr;
+    std::vector<hipEvent_t> e_join;
+    int arenas = 1;                        // activation arenas (2: one per half batch)
+    size_t arena_bytes = 0;
+    bool halves = false;                   // the current forward runs as two concurrent half-batch passes
     size_t workspace_bytes = 0;
     size_t out_count = 0;          // floats per image of the head output
     double flops_per_image = 0;

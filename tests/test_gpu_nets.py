@@ -110,3 +110,27 @@ def test_full_size_v3_608_batch32():
     for i in range(2, 32):
         assert np.array_equal(got32[i], got32[i % 2]), "image %d differs from its twin" % i
     assert rel_err(got32[:2], got2) <= 5e-3
+
+
+@pytest.mark.parametrize("streams", [2, 3])
+def test_multi_stream_forward_and_detect(streams):
+    """yolo_net_options.streams: the batch as independent parts on several HIP streams, each in its own activation
+    arena -> same logits as the single pass (bit-identical where a part sees the same batch size, summation-order noise
+    where the tile differs), same boxes; also a batch that fits one arena, and the per-kernel timed pass"""
+    from tensorflow_yolo_amd.net import engine
+    net, nc = build("v3", 160)
+    w = synth.darknet_stream(net, seed=5, num_classes=nc)
+    x = synth.synthetic_input(6, 160, 160, 3, seed=12)
+    one = engine.HipNetwork(net, dtype="fp16", max_batch=6)
+    one.load_weights(w)
+    many = engine.HipNetwork(net, dtype="fp16", max_batch=6, streams=streams)
+    many.load_weights(w)
+    a, b = one.forward(x).cpu().numpy(), many.forward(x).cpu().numpy()
+    assert rel_err(b, a) <= 5e-3
+    per = (6 + streams - 1) // streams
+    assert rel_err(many.forward(x[:per]).cpu().numpy(), a[:per]) <= 5e-3          # fits arena 0: single pass
+    ra, rb = one.detect(x, 0.3, 0.5), many.detect(x, 0.3, 0.5)
+    ca, cb = ra[1].cpu().numpy(), rb[1].cpu().numpy()
+    assert (np.abs(ca.astype(int) - cb.astype(int)) <= 1).all() and not rb[2].cpu().numpy().any()
+    ms = many.forward_timed(x)
+    assert len(ms) == many.num_kernels and float(np.sum(ms)) > 0
