@@ -34,6 +34,8 @@ WORKLOADS = {
     "tiny-v2-voc-416-b64-fp32": ("v2-tiny", 416, 64, "fp32"),
     "v2-416-b1-fp32": ("v2", 416, 1, "fp32"),
     "v3-416-b32-fp16": ("v3", 416, 32, "fp16"),
+    "v3-608-b8-fp16": ("v3", 608, 8, "fp16"),       # smaller batches of the headline net (tile-choice sanity, latency)
+    "v3-608-b1-fp16": ("v3", 608, 1, "fp16"),
 }
 PEAK = {"fp16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s, MI355X_MICROARCH.md "Chip-level parameters"
 COCO_V2 = [0.57273, 0.677385, 1.87446, 2.06253, 3.33843, 5.47434, 7.88282, 3.52778, 9.77052, 9.16828]
