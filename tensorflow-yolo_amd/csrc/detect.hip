@@ -97,6 +97,12 @@ __device__ __forceinline__ unsigned orderable(float f) {        // monotone floa
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// bytes of the union region { sort keys | sorted boxes (+ suppression bit matrix of the <= 512-candidate path) }
+__host__ __device__ inline size_t nms_union_bytes(size_t cap2) {
+    const size_t u = (cap2 * 29 + 15) & ~(size_t)15;            // max(key 8 B, boxes 8+8+4+4+4+1 = 29 B) per entry
+    return u < 49152 ? 49152 : u;                               // boxes of 512 entries (< 16 KiB) + 512 x 8 x 8 B of mask
+}
+
 // Working storage carve (16-byte aligned): idx u16[n2] | union { key u64[n2] ; boxes } | kept u16[cap].
 // Up to 4096 candidates per image it lives in LDS (dynamic); above (GLOBAL: up to 65536, e.g. a mAP-style
 // threshold of 0.005 on 22 743 rows) the same algorithm runs on a per-image slab of global memory that stays in L2
@@ -116,9 +122,7 @@ __global__ void __launch_bounds__(1024) nms_kernel(const NmsParams p) {
         if (tid == 0) { p.counts[b] = 0; p.status[b] = status; }
         return;
     }
-    // few candidates are the usual case: surplus waves leave before the first barrier (terminated waves do not take part)
-    if (n <= 256) nthr = 256;
-    if (tid >= nthr) return;
+    const bool small = n <= 512;        // the usual case: single-wave sort + suppression bit matrix + single-wave greedy pass
     int n2 = 2;
     while (n2 < n) n2 <<= 1;
     int cap2 = 2;
@@ -136,6 +140,29 @@ __global__ void __launch_bounds__(1024) nms_kernel(const NmsParams p) {
         idx[i] = (unsigned short)i;
     }
     __syncthreads();
+    if (small) {
+        // ~40 compare-exchange stages of <= 256 comparators: one wave runs them back to back (LDS executes a wave's
+        // instructions in order), everybody else waits at ONE barrier instead of taking part in forty
+        if (tid < 64) {
+            for (int k = 2; k <= n2; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = tid; t < (n2 >> 1); t += 64) {
+                        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                        const int l = i | j;
+                        const bool up = (i & k) == 0;
+                        const unsigned long long ki = key[i], kl = key[l];
+                        if ((ki > kl) == up) {
+                            key[i] = kl; key[l] = ki;
+                            const unsigned short s = idx[i]; idx[i] = idx[l]; idx[l] = s;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        __syncthreads();
+    } else
     for (int k = 2; k <= n2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int t = tid; t < (n2 >> 1); t += nthr) {
@@ -158,7 +185,7 @@ __global__ void __launch_bounds__(1024) nms_kernel(const NmsParams p) {
     float *by = bx + n;
     int *bc = reinterpret_cast<int *>(by + n);
     unsigned char *alive = reinterpret_cast<unsigned char *>(bc + n);
-    unsigned short *kept = reinterpret_cast<unsigned short *>(u + (((size_t)cap2 * 29 + 15) & ~(size_t)15));
+    unsigned short *kept = reinterpret_cast<unsigned short *>(u + nms_union_bytes((size_t)cap2));
     __syncthreads();
     for (int i = tid; i < n; i += nthr) {
         const Candidate c = cand[idx[i]];
@@ -169,6 +196,62 @@ __global__ void __launch_bounds__(1024) nms_kernel(const NmsParams p) {
     const double thr = p.iou_threshold;
     int nk = 0;
     bool truncated = false;
+    if (small) {
+        // (1) every thread: one 64-bit word of the suppression matrix, mask[i][w] bit jj = box 64 w + jj (later in the
+        //     sorted order than i) has IoU >= thr with box i -- the same float64 arithmetic as the loop below;
+        // (2) wave 0: greedy pass over the sorted list with the alive set in registers (lane w holds word w):
+        //     alive &= ~mask[i] for every kept i.  Five barriers per image instead of one per survivor.
+        const int W = (n + 63) >> 6;
+        unsigned long long *mask = reinterpret_cast<unsigned long long *>(u + 16384);
+        int *scal = reinterpret_cast<int *>(u + 16384 - 16);                // nk, truncated (the boxes of <= 512 entries end below)
+        for (int item = tid; item < n * W; item += nthr) {
+            const int i = item / W, w = item - i * W;
+            unsigned long long bits = 0;
+            if (64 * w + 63 > i) {
+                const double w1 = bw[i], h1 = bh[i];
+                const double x1 = (double)bx[i], y1 = (double)by[i];
+                const double ax1 = (x1 - w1 / 2.) * 1., ay1 = (y1 - h1 / 2.) * 1.;      // base.py:267-272
+                const double ax2 = (x1 + w1 / 2.) * 1., ay2 = (y1 + h1 / 2.) * 1.;
+                const double a1 = w1 * h1;
+                const int c1 = bc[i];
+                for (int jj = 0; jj < 64; ++jj) {
+                    const int j = 64 * w + jj;
+                    if (j <= i || j >= n) continue;
+                    if (p.mode == YOLO_NMS_PER_CLASS && bc[j] != c1) continue;
+                    const double w2 = bw[j], h2 = bh[j];
+                    const double x2 = (double)bx[j], y2 = (double)by[j];
+                    const double bx1 = (x2 - w2 / 2.) * 1., by1 = (y2 - h2 / 2.) * 1.;
+                    const double bx2 = (x2 + w2 / 2.) * 1., by2 = (y2 + h2 / 2.) * 1.;
+                    const double iw = fmax(fmin(ax2, bx2) - fmax(ax1, bx1), 0.);
+                    const double ih = fmax(fmin(ay2, by2) - fmax(ay1, by1), 0.);
+                    const double inter = iw * ih;
+                    const double uni = fmax(a1 + w2 * h2 - inter, 1e-8);                // base.py:190
+                    if (inter / uni >= thr) bits |= 1ull << jj;                         // base.py:204
+                }
+            }
+            mask[i * 8 + w] = bits;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            unsigned long long alive_w = 0;
+            if (tid < W) alive_w = (tid == W - 1 && (n & 63)) ? ((1ull << (n & 63)) - 1) : ~0ull;
+            for (int i = 0; i < n; ++i) {
+                const int wsel = i >> 6;
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(alive_w & 0xffffffffull), wsel);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(alive_w >> 32), wsel);
+                const unsigned long long wv = ((unsigned long long)hi << 32) | lo;
+                if (!((wv >> (i & 63)) & 1)) continue;
+                if (nk == p.max_boxes) { truncated = true; break; }
+                if (tid == 0) kept[nk] = (unsigned short)i;
+                ++nk;
+                if (tid < W) alive_w &= ~mask[i * 8 + tid];
+            }
+            if (tid == 0) { scal[0] = nk; scal[1] = truncated ? 1 : 0; }
+        }
+        __syncthreads();
+        nk = scal[0];
+        truncated = scal[1] != 0;
+    } else
     for (int i = 0; i < n; ++i) {
         if (!alive[i]) continue;                // final: every earlier survivor's pass ended with a barrier
         if (nk == p.max_boxes) { truncated = true; break; }
@@ -214,8 +297,7 @@ size_t nms_lds_bytes(int cap) {
     size_t cap2 = 2;
     while ((int)cap2 < cap) cap2 <<= 1;
     size_t a = (cap2 * 2 + 15) & ~(size_t)15;           // idx
-    size_t u = (cap2 * 29 + 15) & ~(size_t)15;          // max(key 8 B, boxes 8+8+4+4+4+1 = 29 B) per entry
-    return a + u + cap2 * 2 + 64;                       // + kept
+    return a + nms_union_bytes(cap2) + cap2 * 2 + 64;   // + kept
 }
 
 hipError_t launch_decode(const DecodeParams &p, int batch, hipStream_t s) {
