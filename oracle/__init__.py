@@ -21,4 +21,8 @@ Pinning status
   call sites ``net/layers.py:9-134`` and is cross-checked two independent ways
   (torch conv2d in fp64 vs a naive NumPy direct convolution) in
   ``tests/test_oracle_forward.py``.
+* image preprocessing (``preprocess_ref.py``) -- PARITY UNPINNED:
+  the arithmetic lives in OpenCV (``requirements.txt``: opencv-python, absent);
+  restates OpenCV's published 8-bit INTER_LINEAR fixed-point algorithm and is
+  property-checked in ``tests/test_oracle_golden.py``.
 """
