@@ -187,6 +187,7 @@ int make_conv_params(yolo_net *net, const Kernel &k, const Ptrs &P, int batch, C
     p.cpt_shift = k.cpt == 1 ? 0 : k.cpt == 2 ? 1 : 2;
     p.wrow_bytes = (uint32_t)k.ktiles * 128;
     p.leaky = k.leaky; p.outmode = k.outmode; p.has_res = k.has_res;
+    p.f32 = dtype == YOLO_DTYPE_F32;
     const int ch = k.cfg == CFG_N32 ? 8 : 16;
     const int oepc = p.out_f32 ? 4 : epc;
     p.vec_out = (k.cout % ch == 0) && (k.out.ld % oepc == 0) && ((k.out.base + k.out.coff) % oepc == 0) &&
@@ -210,19 +211,22 @@ int make_conv_params(yolo_net *net, const Kernel &k, const Ptrs &P, int batch, C
 }
 
 // the LDS-DMA kernels take fp16 convs whose Cin is a multiple of 4 chunks (32 channels)
+// float32 nets: only the tap-reuse kernel (3x3/1) has a float32 instantiation besides the 4-wave kernel
 bool dma_eligible(const yolo_net *net, const Kernel &k) {
-    return net->opt.dtype == YOLO_DTYPE_F16 && k.cpt % 4 == 0;
+    if (k.cpt % 4) return false;
+    return net->opt.dtype == YOLO_DTYPE_F16 || (k.ksize == 3 && k.stride == 1);
 }
 // tile 0 = the 4-wave kernel of conv.hip with the planner's cfg (always available)
 bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile) {
     if (tile == 0) return true;
+    if (net->opt.dtype == YOLO_DTYPE_F32 && !dma_cfg_is_tap(tile)) return false;
     return dma_eligible(net, k) && dma_cfg_valid(tile, k.cout, k.cpt, true, k.ksize, k.stride, k.in.W);
 }
 
 // tile < 0: heuristic (choose_dma_cfg); 0: 4-wave kernel of conv.hip; > 0: conv_dma.hip tile id
 hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParams &p, int tile, hipStream_t s) {
-    if (!dma_eligible(net, k)) tile = 0;
-    else if (tile < 0) tile = choose_dma_cfg(p.M, k.cout, k.cpt, p.taps, k.has_res, true, k.stride, k.in.W);
+    if (!dma_eligible(net, k) || (tile > 0 && !conv_tile_valid(net, k, tile))) tile = 0;
+    else if (tile < 0) tile = choose_dma_cfg(p.M, k.cout, k.cpt, p.taps, k.has_res, true, k.stride, k.in.W, net->opt.dtype == YOLO_DTYPE_F32);
     return tile > 0 ? launch_conv_dma(p, tile, s) : launch_conv(p, net->opt.dtype, k.cfg, k.perchunk != 0, s);
 }
 
@@ -519,10 +523,10 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         }
         int tile = 0;       // which kernel runs at max_batch (bench.py runs at max_batch)
         if (dma_eligible(net, k))
-            tile = k.tile >= 0 ? k.tile : choose_dma_cfg((net->opt.max_batch + net->arenas - 1) / net->arenas * li.H * li.W, k.cout, k.cpt, k.ksize * k.ksize, k.has_res, true, k.stride, k.in.W);
+            tile = k.tile >= 0 ? k.tile : choose_dma_cfg((net->opt.max_batch + net->arenas - 1) / net->arenas * li.H * li.W, k.cout, k.cpt, k.ksize * k.ksize, k.has_res, true, k.stride, k.in.W, net->opt.dtype == YOLO_DTYPE_F32);
         if (tile > 0) {
             out->variant = 8 + tile;
-            snprintf(out->name, sizeof out->name, "conv_igemm_dma<f16,%s>", dma_cfg_name(tile));
+            snprintf(out->name, sizeof out->name, "conv_igemm_dma<%s,%s>", t, dma_cfg_name(tile));
         } else {
             snprintf(out->name, sizeof out->name, "conv_igemm<%s,N%d,%s>", t, k.cfg == CFG_N128 ? 128 : k.cfg == CFG_N64 ? 64 : 32,
                      k.perchunk ? "perchunk" : "uniform");

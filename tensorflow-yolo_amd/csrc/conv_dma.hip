@@ -238,6 +238,7 @@ static const DmaCfg kCfgs[] = {
 static const int kNumCfgs = 15;
 static const int kFirstTapCfg = 8, kLastTapCfg = 13;
 static inline bool is_tap_cfg(int cfg) { return cfg >= kFirstTapCfg && cfg <= kLastTapCfg; }
+bool dma_cfg_is_tap(int cfg) { return is_tap_cfg(cfg); }
 
 // Pick the block tile that minimises rounds x tile time on 256 CUs (tail quantisation matters:
 // e.g. 38x38x512 at batch 32 is 362 tiles of 256x256 = 2 rounds at 71 % but 722 of 256x128 = 3 at 94 %).
@@ -279,19 +280,23 @@ static const TileCost kCost[] = {
     {1.10f, 1.50f, 0.70f, 8.0f},        // 14: 128x128 K32 S3, three per CU: 1x1 layers only (short K, memory / latency bound)
 };
 
-int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W) {
+int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W, bool tap_only) {
     const int ksize = taps == 9 ? 3 : 1;
     const char *force = getenv("YOLO_CONV_TILE");
-    if (force && *force && dma_cfg_valid(atoi(force), cout, cin_chunks, v1_ok, ksize, stride, W)) return atoi(force);
+    if (force && *force && dma_cfg_valid(atoi(force), cout, cin_chunks, v1_ok, ksize, stride, W) && (!tap_only || atoi(force) == 0 || is_tap_cfg(atoi(force))))
+        return atoi(force);
     const int fallback = v1_ok ? 0 : -1;
     if (cout <= 64) {   // narrow, bandwidth-bound layers: 3x3/1 with tap reuse (304x304 32->64: 239 us vs 273 on the 64x512 tile)
         if (M >= 8192 && dma_cfg_valid(13, cout, cin_chunks, v1_ok, ksize, stride, W)) return 13;
-        return dma_cfg_valid(7, cout, cin_chunks, v1_ok, ksize, stride, W) && M >= 8192 ? 7 : fallback;
+        return !tap_only && dma_cfg_valid(7, cout, cin_chunks, v1_ok, ksize, stride, W) && M >= 8192 ? 7 : fallback;
     }
     const double k64 = taps * cin_chunks / 8.0;         // 64-deep K tiles
     int best = fallback;
     double best_t = 1e300;
     for (int c = 0; c < kNumCfgs; ++c) {
+        // float32 nets: only conv_tap.hip has a float32 instantiation, and it beats the 4-wave kernel by ~10 % on every 3x3/1
+        // layer measured (tiny-YOLOv2 b64: 1024->1024 at 13x13 2.26 -> 2.06 ms), so the 4-wave kernel is only the fallback
+        if (tap_only && !is_tap_cfg(c)) continue;
         if (c == 12 && W <= 110) continue;      // the padded-linear tiles fit and measured faster (104x104: 70 vs 84 us)
         if (c == 14 && taps != 1) continue;     // measured 10-20 % slower than the larger tiles on every 3x3 layer
         if (c == 7 || c == 13 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;

@@ -57,9 +57,10 @@ __device__ __forceinline__ int tap_swz_w(int r) { return (0x78 >> (2 * ((r >> 2)
 // a block owns TH x 16 output pixels (TH = NB / 16, fragment = one tile row), the patch is (TH + 2) rows of PW = 24
 // slots (18 used: PW a multiple of 8 keeps the swizzle phase of every fragment row equal, so fragment offsets stay
 // immediates), tap shift kh * 24 + kw; pixels of partial tiles outside the image are computed and dropped.
-template <int WM, int WN, int TM, int TP, int PRG, int OCC, int MODE = 1>
+// T = _Float16 (32-channel slices, mfma_f32_16x16x32_f16) or float (16-channel slices, four mfma_f32_16x16x4f32 per
+// fragment pair: the exact fp32 FMA chain of conv.hip) -- the LDS geometry is in 16-byte chunks either way.
+template <typename T, int WM, int WN, int TM, int TP, int PRG, int OCC, int MODE = 1>
 __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams p) {
-    typedef _Float16 T;
     constexpr int NW = 8;
     constexpr int S = 3;                    // weight ring slots (9 taps per slice: slot = tap % 3)
     constexpr int ROWB = 64;
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
             ok = ok && x < p.W && y < p.H;
         }
         const long long e = (long long)n * p.in_img_stride + ((long long)y * p.W + x) * p.in_ld + p.in_coff;
-        b_off[j] = ok ? (uint32_t)(e * 2) + csw_p : YOLO_INVALID_OFF;
+        b_off[j] = ok ? (uint32_t)(e * (long long)sizeof(T)) + csw_p : YOLO_INVALID_OFF;
     }
 
     const int C = p.cin_chunks >> 2;        // 32-channel slices
@@ -262,13 +263,25 @@ hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
     if (p.ksize != 3 || p.stride != 1 || p.pad != 1 || p.Ho != p.H || p.Wo != p.W || (p.cin_chunks & 3) || !conv_tap_fits(variant, p.W))
         return hipErrorInvalidValue;
     const dim3 grid((unsigned)p.n_blocks);
+    if (p.f32) {
+        switch (variant) {
+        case 0: hipLaunchKernelGGL((conv3x3_tap_kernel<float, 2, 4, 4, 4, 26, 4>), grid, dim3(512), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((conv3x3_tap_kernel<float, 2, 4, 8, 4, 26, 2>), grid, dim3(512), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((conv3x3_tap_kernel<float, 2, 4, 4, 3, 26, 4>), grid, dim3(512), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((conv3x3_tap_kernel<float, 2, 4, 4, 2, 28, 4>), grid, dim3(512), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((conv3x3_tap_kernel<float, 2, 4, 4, 4, 27, 4, 2>), grid, dim3(512), 0, s, p); break;
+        case 5: hipLaunchKernelGGL((conv3x3_tap_kernel<float, 1, 8, 4, 2, 27, 4, 2>), grid, dim3(512), 0, s, p); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (variant) {
-    case 0: hipLaunchKernelGGL((conv3x3_tap_kernel<2, 4, 4, 4, 26, 4>), grid, dim3(512), 0, s, p); break;
-    case 1: hipLaunchKernelGGL((conv3x3_tap_kernel<2, 4, 8, 4, 26, 2>), grid, dim3(512), 0, s, p); break;
-    case 2: hipLaunchKernelGGL((conv3x3_tap_kernel<2, 4, 4, 3, 26, 4>), grid, dim3(512), 0, s, p); break;
-    case 3: hipLaunchKernelGGL((conv3x3_tap_kernel<2, 4, 4, 2, 28, 4>), grid, dim3(512), 0, s, p); break;
-    case 4: hipLaunchKernelGGL((conv3x3_tap_kernel<2, 4, 4, 4, 27, 4, 2>), grid, dim3(512), 0, s, p); break;
-    case 5: hipLaunchKernelGGL((conv3x3_tap_kernel<1, 8, 4, 2, 27, 4, 2>), grid, dim3(512), 0, s, p); break;
+    case 0: hipLaunchKernelGGL((conv3x3_tap_kernel<_Float16, 2, 4, 4, 4, 26, 4>), grid, dim3(512), 0, s, p); break;
+    case 1: hipLaunchKernelGGL((conv3x3_tap_kernel<_Float16, 2, 4, 8, 4, 26, 2>), grid, dim3(512), 0, s, p); break;
+    case 2: hipLaunchKernelGGL((conv3x3_tap_kernel<_Float16, 2, 4, 4, 3, 26, 4>), grid, dim3(512), 0, s, p); break;
+    case 3: hipLaunchKernelGGL((conv3x3_tap_kernel<_Float16, 2, 4, 4, 2, 28, 4>), grid, dim3(512), 0, s, p); break;
+    case 4: hipLaunchKernelGGL((conv3x3_tap_kernel<_Float16, 2, 4, 4, 4, 27, 4, 2>), grid, dim3(512), 0, s, p); break;
+    case 5: hipLaunchKernelGGL((conv3x3_tap_kernel<_Float16, 1, 8, 4, 2, 27, 4, 2>), grid, dim3(512), 0, s, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -85,6 +85,7 @@ struct ConvParams {
     int cin_chunks;            // 16-byte chunks per tap (storage channels / EPC)
     uint32_t wrow_bytes;
     int leaky, has_res, outmode, out_f32, vec_out, vec_res;
+    int f32;                   // elements of input / weights / residual are float32 (else fp16)
     int n_tiles_n, n_blocks;
     int dbg;                   // experiment flags (YOLO_CONV_DBG): 1 skip steady-state DMA, 2 skip MFMA phase
     int qW, qHW, Mq;           // conv_tap.hip: padded-linear pixel grid, row stride W+1, image stride (H+1)(W+1), total
@@ -208,8 +209,9 @@ struct NmsParams {
 hipError_t launch_conv(const ConvParams &p, int dtype, int cfg, bool perchunk, hipStream_t s);
 // conv_dma.hip: 8-wave LDS-DMA kernel for the heavy fp16 layers.  choose_dma_cfg returns 0 when the
 // 4-wave kernel of conv.hip should run, else the tile id for launch_conv_dma.
-int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W);   // -1: no DMA tile and no 4-wave kernel fits
+int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W, bool tap_only = false);   // -1: no DMA tile and no 4-wave kernel fits
 bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok, int ksize, int stride, int W);
+bool dma_cfg_is_tap(int cfg);
 int dma_cfg_bkc(int cfg);
 hipError_t launch_conv_dma(const ConvParams &p, int cfg, hipStream_t s);
 hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s);       // conv_tap.hip: 3x3/1 with tap reuse

@@ -17,7 +17,7 @@ def family(name):
     m = re.search(r"conv_igemm_dma_kernel<([\d, ]+)>", name)
     if m:
         return "conv_igemm_dma<f16,%s>" % DMA.get(tuple(int(v) for v in m.group(1).split(",")), m.group(1))
-    m = re.search(r"conv3x3_tap_kernel<([\d, ]+)>", name) or re.search(r"conv3x3_tap_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+    m = re.search(r"conv3x3_tap_kernel<(?:_Float16|float), ([\d, ]+)>", name) or re.search(r"conv3x3_tap_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
     if m:
         v = tuple(int(x) for x in (m.group(1).split(",") if m.lastindex == 1 else m.groups()))
         return "conv_igemm_dma<f16,%s>" % {(2, 4, 4, 4): "128x256,tap9,x2", (2, 4, 8, 4): "256x256,tap9", (2, 4, 4, 3): "128x192,tap9,x2",
