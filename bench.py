@@ -9,7 +9,14 @@ A "step" = one pass of the hot path over one synthetic batch resident in HBM: fl
 libyolo_hip detect (75 fused convs + decode + NMS) [-> RCCL all-gather of the fixed-size box
 records when N > 1].  Images shard over ranks (weak scaling: every rank runs the full per-GPU batch).
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a child
+`python -m torch.distributed.run ... bench.py` started before this process touches the GPU; rank 0's JSON line is the
+child's stdout, the exit code is the child's).
+
 Rank 0 prints ONE JSON line with the contract fields plus
+  "parity":       the metric's second half, "post-NMS box-set match vs CPU ref": two images through the HIP path and
+                  through the CPU fp32 oracle pipeline OUTSIDE the timed region -- max |logit - oracle logit| and the
+                  post-NMS box sets compared under the margin rule of oracle/parity.py
   "roofline":     dominant kernel family (the implicit-GEMM conv tile with most device time): algorithmic FLOPs of its launches
                   / their device time measured with hipEvents on the launch stream (instrumented steps
                   run right after the timed region; the events add bubbles so they never time `value`)
@@ -43,7 +50,7 @@ VOC_TINY = [1.08, 1.19, 3.42, 4.41, 6.63, 11.38, 9.42, 5.11, 16.62, 10.52]
 COCO_V3 = [10, 13, 16, 30, 33, 23, 30, 61, 62, 45, 59, 119, 116, 90, 156, 198, 373, 326]
 
 
-def make_model(kind, size, batch, dtype, seed=0, streams=0):
+def make_model(kind, size, batch, dtype, seed=0, streams=0, max_boxes=256):
     from tensorflow_yolo_amd import YoloV2, YoloV2Tiny, YoloV3
     from tensorflow_yolo_amd.net import synth
     cls, anchors, ncls = {"v3": (YoloV3, COCO_V3, 80), "v2": (YoloV2, COCO_V2, 80), "v2-tiny": (YoloV2Tiny, VOC_TINY, 20)}[kind]
@@ -52,14 +59,25 @@ def make_model(kind, size, batch, dtype, seed=0, streams=0):
     net = cls.create_network(np.reshape(anchors, [-1, 2]), names, False, input_shape=(size, size, 3))
     hg, frac = synth.HEAD_DEFAULTS[kind]
     w = synth.darknet_stream(net, seed=seed, num_classes=ncls, head_gain=hg, obj_bias=0.0)
-    model.build(anchors, names, (size, size, 3), dtype=dtype, max_batch=batch, weights=w, streams=streams)
+    model.build(anchors, names, (size, size, 3), dtype=dtype, max_batch=batch, weights=w, streams=streams, max_boxes=max_boxes)
     # data-dependent objectness prior (uses the product's own forward): a realistic handful of candidates
     w = synth.calibrate_model(model, synth.synthetic_input(min(batch, 2), size, size, 3, seed=999), frac)
     return model, w, anchors, ncls
 
 
-def cpu_baseline(kind, size, w, anchors, ncls, budget_s=20.0):
-    """Oracle forward + decode + NMS on the host cores, bounded sample (never the thing shipped)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(kind, size, w, anchors, ncls, budget_s=20.0, time_it=True):
+    """Oracle forward + decode + NMS on the host cores, bounded sample (never the thing shipped).
+    Returns (cpu_baseline dict or None, x [2 images], oracle fp32 logits of x) -- the logits feed the parity check."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import to_oracle
@@ -86,8 +104,12 @@ def cpu_baseline(kind, size, w, anchors, ncls, budget_s=20.0):
             decode_ref.find_bounding_boxes_v3(logits, 0.5, 0.6, sc)
         else:
             decode_ref.find_bounding_boxes_v2(logits, 0.5, 0.6, anchors, ncls)
+        return logits
 
-    one()                                   # warm-up (thread pool, allocator)
+    ref_logits = one()                      # warm-up (thread pool, allocator); its logits are the parity reference
+    if not time_it:
+        torch.set_num_threads(default_threads)
+        return None, x, ref_logits
     t0 = time.perf_counter()
     n = 0
     while True:
@@ -97,9 +119,37 @@ def cpu_baseline(kind, size, w, anchors, ncls, budget_s=20.0):
         if dt > budget_s or n >= 64:
             break
     torch.set_num_threads(default_threads)
-    return {"value": round(n / dt, 3), "unit": "images/sec", "cores": int(cores), "kind": "port",
-            "sample": "%d images %dx%d, CPU oracle (torch-CPU fp32 restatement of the reference's TF path + NumPy decode/NMS), "
-                      "%.1f s" % (n, size, size, dt)}
+    return ({"value": round(n / dt, 3), "unit": "images/sec", "cores": int(cores), "kind": "port",
+             "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
+             "sample": "%d images %dx%d, CPU oracle (torch-CPU fp32 restatement of the reference's TF path + NumPy decode/NMS, "
+                       "not TensorFlow), %.1f s" % (n, size, size, dt)}, x, ref_logits)
+
+
+def parity_report(model, kind, size, anchors, ncls, x, ref_logits, threshold, iou_threshold):
+    """HIP path vs the CPU fp32 oracle pipeline on the images `x` (oracle/parity.py); outside the timed region."""
+    from oracle import decode_ref, parity
+    from tensorflow_yolo_amd.net import engine as yengine
+    eng = model.net.engine
+    got_logits = eng.forward(x).cpu().numpy()
+    recs, _ = yengine.records_to_host(*eng.detect(x, threshold, iou_threshold))
+    if kind == "v3":
+        return parity.check(ref_logits, got_logits, recs, 3, threshold, iou_threshold, scales=decode_ref.v3_scales(anchors, (size, size)))
+    return parity.check(ref_logits, got_logits, recs, 2, threshold, iou_threshold, anchors=anchors, num_classes=ncls)
+
+
+def launch_workers(n):
+    """`python bench.py --gpus N` as the driver calls it: start the N ranks as a child torch.distributed.run job.  This
+    process has not touched the GPU (torch is not even imported yet), nothing is exec'd; the child's exit code is ours."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -109,6 +159,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="v3-608-b32-fp16", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the 2-image parity check against the CPU oracle")
+    ap.add_argument("--max-boxes", type=int, default=256, help="box records per image (SURVEY 8e: K_max = 256 -> 196.7 KB per rank)")
     ap.add_argument("--autotune", action="store_true", help="time every conv tile per layer on the device first (default: built-in rules)")
     ap.add_argument("--streams", type=int, default=0, help="run every batch as this many independent parts on as many HIP streams "
                     "(overlaps the kernels' tails; the per-kernel roofline figures then describe one part's launches run alone)")
@@ -116,6 +168,9 @@ def main():
     ap.add_argument("--iou-threshold", type=float, default=0.6)
     ap.add_argument("--dump-kernels", default=None, help="write the per-kernel timing table (JSON) here")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:        # before anything touches the GPU
+        sys.exit(launch_workers(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -125,8 +180,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world), file=sys.stderr)
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        print("bench.py: rank %d needs GPU %d, torch sees %d device(s): no GPU, no benchmark (there is no CPU path)"
+              % (rank, local_rank, torch.cuda.device_count() if torch.cuda.is_available() else 0), file=sys.stderr)
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -134,7 +193,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     kind, size, batch, dtype = WORKLOADS[args.workload]
-    model, w, anchors, ncls = make_model(kind, size, batch, dtype, streams=args.streams)
+    model, w, anchors, ncls = make_model(kind, size, batch, dtype, streams=args.streams, max_boxes=args.max_boxes)
     eng = model.net.engine
     from tensorflow_yolo_amd.net import synth
     # two different resident input batches, alternated, so no step re-reads the previous step's input
@@ -144,10 +203,9 @@ def main():
     from tensorflow_yolo_amd.net import dist as ydist
 
     def step(i):
-        boxes, counts, status = eng.detect(xs[i & 1], args.threshold, args.iou_threshold)
-        if world > 1:       # the only exchange of the path: fixed-size box records, rank order == image order
-            ydist.gather_records(boxes, counts, status)
-        return boxes, counts, status
+        # forward + decode + NMS of this rank's images (one C call) and, for N > 1, the path's only exchange: ONE all-gather
+        # of the fixed-size record buffer (rank order == image order) -- the same function the gloo CPU tests drive
+        return ydist.detect_sharded(eng, xs[i & 1], args.threshold, args.iou_threshold)
 
     def fence():
         if world > 1:
@@ -168,8 +226,8 @@ def main():
         elapsed = float(t.item())
     st = status.cpu().numpy()
     nboxes = counts.cpu().numpy()
-    if (st & 1).any():
-        raise RuntimeError("candidate overflow during the benchmark: result would not match the reference")
+    if st.any():
+        raise RuntimeError("candidate / box-record capacity exceeded during the benchmark: result would not match the reference")
 
     out = None
     if rank == 0:
@@ -192,7 +250,8 @@ def main():
         dom = max(fam, key=lambda n: fam[n]["ms"])
         d = fam[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK[dtype], "unit": "TFLOP/s",
+        dom_symbol = next(ki.symbol.decode() for ki in infos if ki.name.decode() == dom)
+        roof = {"bound": "mfma", "kernel": dom, "kernel_symbol": dom_symbol, "achieved": round(achieved, 2), "peak": PEAK[dtype], "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK[dtype], 4), "traffic": None,
                 "launches_per_step": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 5),
                 "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
@@ -202,14 +261,15 @@ def main():
         tj = os.path.join(ROOT, "profiles", "traffic.json")      # HBM bytes per launch from rocprofv3 --pmc passes, if recorded
         if os.path.exists(tj):
             try:
-                rec = json.load(open(tj)).get(args.workload, {}).get(dom)
+                tw = json.load(open(tj)).get(args.workload, {})
+                rec = tw.get(dom_symbol) or tw.get(dom)
                 if rec:     # recorded under rocprofv3 --pmc for this kernel family (may predate a retune)
                     roof["traffic"] = rec["hbm_bytes_per_launch"]
                     roof["traffic_detail"] = dict(rec, source="profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)")
             except Exception:
                 pass
         if args.dump_kernels:
-            rows = [{"kernel": k, "name": ki.name.decode(), "layer": ki.layer, "k": ki.ksize, "s": ki.stride, "cin": ki.cin,
+            rows = [{"kernel": k, "name": ki.name.decode(), "symbol": ki.symbol.decode(), "layer": ki.layer, "k": ki.ksize, "s": ki.stride, "cin": ki.cin,
                      "cout": ki.cout, "out_hw": [ki.out_h, ki.out_w], "ms": round(float(ms[k]), 5),
                      "tflops": round(ki.flops * batch / (ms[k] * 1e-3) / 1e12, 2) if ms[k] > 0 else 0.0,
                      "gbps": round((ki.bytes * batch + ki.weight_bytes) / (ms[k] * 1e-3) / 1e9, 1) if ms[k] > 0 else 0.0}
@@ -230,10 +290,12 @@ def main():
             "roofline": roof,
             "forward_frac_of_mfma_peak": round(eng.flops_per_image * total_images / elapsed / 1e12 / (PEAK[dtype] * world), 4),
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(kind, size, w, anchors, ncls)
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = out["parity"] = None
+        if world == 1 and not (args.no_cpu_baseline and args.no_parity):
+            base, xb, ref_logits = cpu_baseline(kind, size, w, anchors, ncls, time_it=not args.no_cpu_baseline)
+            out["cpu_baseline"] = base
+            if not args.no_parity:
+                out["parity"] = parity_report(model, kind, size, anchors, ncls, xb, ref_logits, args.threshold, args.iou_threshold)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define YOLO_HIP_ABI_VERSION 1
+#define YOLO_HIP_ABI_VERSION 2      /* 2: yolo_kernel_info.symbol */
 
 enum yolo_status {
     YOLO_OK = 0,
@@ -83,12 +83,16 @@ typedef struct yolo_net_options {
     int32_t max_batch;      /* buffers are planned for this many images                        */
     int32_t keep_all;       /* 1: no activation-buffer reuse, so yolo_net_read_layer works     */
     int32_t cand_capacity;  /* candidates per image the decode stage can hold (0 -> 4096; up to
-                             * 4096 sort + NMS run in LDS, up to 65536 on global-memory slabs)  */
+                             * 4096 sort + NMS run in LDS, up to 65536 on global-memory slabs; an image
+                             * with at most 512 candidates always takes the single-wave LDS path)    */
     int32_t max_boxes;      /* records per image written by detect / decode_nms (0 -> 256)     */
     int32_t streams;        /* 0/1: one pass on the caller's stream; 2..4: the batch runs as that many independent
                              * parts on the caller's + internal streams (overlaps the kernels' tails; the
                              * environment variable YOLO_STREAMS sets the default when this is 0)          */
-    int32_t reserved[2];
+    int32_t force_tile;     /* 0: per-layer tile choice (cost model / autotune); t + 1: run conv tile id t on every
+                             * conv layer that accepts it (0 = 4-wave kernel, 1-7 and 14 LDS-DMA tiles, 8-13 tap-reuse
+                             * tiles): test and tuning hook, any value gives the same results up to summation order   */
+    int32_t reserved[1];
 } yolo_net_options;
 
 /* Result record; field names follow net/base.py:257-272 BoundingBox. */
@@ -161,7 +165,10 @@ typedef struct yolo_kernel_info {
     double flops;               /* conv: 2*Ho*Wo*Cout*k*k*Cin, else 0                            */
     double bytes;               /* input + output (+ residual) elements * element size           */
     double weight_bytes;        /* packed weights + bias read once per launch (not per image)    */
-    char name[64];              /* kernel symbol family, e.g. "conv_igemm<f16,N128,uniform>"     */
+    char name[64];              /* readable label of the kernel family, e.g. "conv_igemm_dma<f16,128x256,tap9,x2>" */
+    char symbol[160];           /* the kernel's name exactly as rocprofv3 --kernel-trace prints it, e.g.
+                                 * "void yolo::conv3x3_tap_kernel<false, 2, 4, 4, 4, 26, 4, 1>(yolo::ConvParams)":
+                                 * joins roofline.kernel_symbol of bench.py to the kernel_stats CSVs under profiles/; "" = no launch */
 } yolo_kernel_info;
 int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out);
 
@@ -189,7 +196,10 @@ int yolo_preprocess_resize(const uint8_t *src_dev, int src_h, int src_w, int src
                            int swap_rb, void *stream);
 
 /* NMS of a HOST list (x,y,w,h as double, prob float, class int; scan order = index).  Synchronous;
- * allocates its own scratch.  keep_idx receives the indices of survivors in output order. */
+ * allocates its own scratch.  keep_idx receives the indices of survivors in output order.
+ * x and y are rounded to float32 before the IoU arithmetic: that is the type the reference's decode gives them
+ * (net/v2.py:112-113, net/v3.py:129-130 under NumPy 2) and what every golden vector holds; a caller passing
+ * float64 centres that are not float32 values gets the float32-rounded result (w, h stay float64). */
 int yolo_nms_host(const double *xywh, const float *prob, const int32_t *class_idx, int n, double iou_threshold,
                   int nms_mode, int32_t *keep_idx, int32_t *n_keep);
 

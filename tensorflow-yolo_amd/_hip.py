@@ -9,13 +9,16 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enum yolo_op
 OP_INPUT, OP_CONV, OP_MAXPOOL, OP_ROUTE, OP_REORG, OP_SHORTCUT, OP_UPSAMPLE, OP_YOLO, OP_DETECTION = range(9)
 DTYPE_F32, DTYPE_F16 = 0, 1
 NMS_AGNOSTIC, NMS_PER_CLASS = 0, 1
 MAX_SRC, MAX_ANCHORS, MAX_SCALES = 4, 8, 4
+# Records per image every Python entry point asks for unless told otherwise.  The reference's lists are unbounded
+# (net/base.py:195-209); 1024 covers every YOLOv2 head (845 rows) and exceeding it raises (engine.check_status).
+DEFAULT_MAX_BOXES = 1024
 
 
 class LayerDesc(C.Structure):
@@ -28,7 +31,7 @@ class LayerDesc(C.Structure):
 
 class NetOptions(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("max_batch", C.c_int32), ("keep_all", C.c_int32),
-                ("cand_capacity", C.c_int32), ("max_boxes", C.c_int32), ("streams", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("cand_capacity", C.c_int32), ("max_boxes", C.c_int32), ("streams", C.c_int32), ("force_tile", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class Box(C.Structure):
@@ -45,7 +48,8 @@ class HeadDesc(C.Structure):
 class KernelInfo(C.Structure):
     _fields_ = [("kind", C.c_int32), ("layer", C.c_int32), ("variant", C.c_int32), ("ksize", C.c_int32),
                 ("stride", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("out_h", C.c_int32), ("out_w", C.c_int32),
-                ("flops", C.c_double), ("bytes", C.c_double), ("weight_bytes", C.c_double), ("name", C.c_char * 64)]
+                ("flops", C.c_double), ("bytes", C.c_double), ("weight_bytes", C.c_double), ("name", C.c_char * 64),
+                ("symbol", C.c_char * 160)]
 
 
 # name -> (restype, argtypes); every symbol include/yolo_hip.h declares

@@ -24,6 +24,10 @@ static int fail(int code, const std::string &msg) {
     return code;
 }
 
+namespace {
+bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile);
+}
+
 extern "C" {
 
 int yolo_hip_abi_version(void) { return YOLO_HIP_ABI_VERSION; }
@@ -53,6 +57,9 @@ int yolo_net_create(const yolo_layer_desc *layers, int n_layers, const yolo_net_
         delete net;
         return fail(rc, "yolo_net_create: " + err);
     }
+    if (net->opt.force_tile > 0)        // test / tuning hook: one tile id on every conv that accepts it
+        for (Kernel &k : net->kernels)
+            if (k.kind == K_CONV && k.stem < 2 && conv_tile_valid(net, k, net->opt.force_tile - 1)) k.tile = net->opt.force_tile - 1;
     *out = net;
     return YOLO_OK;
 }
@@ -491,6 +498,7 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
     const Kernel &k = net->kernels[kernel];
     memset(out, 0, sizeof *out);
     out->kind = k.kind; out->layer = k.layer;
+    auto set_symbol = [&](const std::string &sym) { snprintf(out->symbol, sizeof out->symbol, "%s", sym.c_str()); };
     const char *t = net->opt.dtype == YOLO_DTYPE_F16 ? "f16" : "f32";
     auto elems = [](const View &v) { return (double)v.H * v.W * v.C; };
     auto esz = [&](const View &v) { return v.f32 ? 4.0 : (double)net->esize; };
@@ -512,6 +520,7 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
             out->bytes = (double)f.in.H * f.in.W * 3 * 4 + elems(k.out) * esz(k.out);
             out->weight_bytes += 28.0 * f.cout * 4;
             snprintf(out->name, sizeof out->name, "conv_stem<f16,3-32-64>");
+            set_symbol("yolo::stem_v3_kernel(yolo::StemParams)");
             if (kernel + 1 < (int)net->kernels.size() && net->kernels[kernel + 1].stem == 3) {
                 const Kernel &t3 = net->kernels[kernel + 1];
                 out->flops += 2.0 * li.H * li.W * t3.cout * t3.cin;
@@ -527,7 +536,9 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         if (tile > 0) {
             out->variant = 8 + tile;
             snprintf(out->name, sizeof out->name, "conv_igemm_dma<%s,%s>", t, dma_cfg_name(tile));
+            set_symbol(dma_cfg_symbol(tile, net->opt.dtype == YOLO_DTYPE_F32));
         } else {
+            set_symbol(conv_symbol(net->opt.dtype, k.cfg, k.perchunk != 0));
             snprintf(out->name, sizeof out->name, "conv_igemm<%s,N%d,%s>", t, k.cfg == CFG_N128 ? 128 : k.cfg == CFG_N64 ? 64 : 32,
                      k.perchunk ? "perchunk" : "uniform");
         }
@@ -538,7 +549,9 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         out->weight_bytes = 28.0 * k.cout * 4;
         snprintf(out->name, sizeof out->name, k.pool_fused ? "conv_first_pool<%s,%d>" : "conv_first<%s,%d>", t, k.cout);
         if (k.pool_fused) { out->out_h = k.in.H; out->out_w = k.in.W; out->flops = 2.0 * k.in.H * k.in.W * k.cout * 27; }
-        if (k.stem == 1) {          // no launch of its own: accounted for in the conv_stem kernel that follows
+        set_symbol(first_symbol(net->opt.dtype, k.cout, k.pool_fused != 0));
+        if (k.stem == 1) {
+            out->symbol[0] = 0;          // no launch of its own: accounted for in the conv_stem kernel that follows
             out->flops = 0; out->bytes = 0; out->weight_bytes = 0;
             snprintf(out->name, sizeof out->name, "conv_first<fused into conv_stem>");
         }
@@ -546,6 +559,10 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         out->out_h = k.out.H; out->out_w = k.out.W; out->cout = k.out.C; out->cin = k.in.C;
         out->bytes = elems(k.in) * (k.in.f32 ? 4.0 : net->esize) + elems(k.out) * esz(k.out) + (k.has_res ? elems(k.in2) * net->esize : 0.0);
         snprintf(out->name, sizeof out->name, "%s<%s>", k.kind == K_PREP ? "prep" : k.kind == K_POOL ? "pool" : "eltwise", t);
+        const int epc = net->epc;       // pool: the 16-byte-vector instantiation runs when every stride is chunk-aligned (aux.hip)
+        const bool vec = k.kind == K_POOL && k.in.C % epc == 0 && k.in.ld % epc == 0 && k.out.ld % epc == 0 && (k.in.base + k.in.coff) % epc == 0 &&
+                         (k.out.base + k.out.coff) % epc == 0 && k.in.img_stride % epc == 0 && k.out.img_stride % epc == 0;
+        set_symbol(aux_symbol(k.kind, net->opt.dtype, vec));
     }
     return YOLO_OK;
 }

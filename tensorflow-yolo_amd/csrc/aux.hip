@@ -2,6 +2,7 @@
 // element-wise fallback (standalone shortcut / upsample / reorg / concat-copy / f32 convert) the
 // planner uses when a fusion into a conv epilogue is not possible.
 #include "yolo_internal.h"
+#include <type_traits>
 
 namespace yolo {
 
@@ -9,8 +10,9 @@ typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 
 // feed point of the graph (net/layers.py:106-109): float32 NHWC -> T NHWC with the channel count
 // padded to one 16-byte chunk (zeros), so the first conv can run the chunked implicit GEMM.
-template <typename T>
+template <bool F32>
 __global__ void __launch_bounds__(256) prep_kernel(const PrepParams p) {
+    typedef typename std::conditional<F32, float, _Float16>::type T;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long px = (long long)blockIdx.x * blockDim.x + threadIdx.x; px < p.pixels; px += stride) {
         const float *src = p.in + px * p.C;
@@ -28,8 +30,9 @@ __global__ void __launch_bounds__(256) prep_kernel(const PrepParams p) {
 
 // net/layers.py:70-81.  stride 2: zero pad (0 before, 1 after) then 2x2 VALID -- the pad row/col is
 // only read for odd H/W and then takes part in the max as 0.  stride 1: TF SAME, window clipped.
-template <typename T, bool VEC>
+template <bool F32, bool VEC>
 __global__ void __launch_bounds__(256) pool_kernel(const PoolParams p) {
+    typedef typename std::conditional<F32, float, _Float16>::type T;
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int STEP = VEC ? EPC : 1;
     const int cchunks = (p.C + STEP - 1) / STEP;
@@ -82,8 +85,9 @@ __global__ void __launch_bounds__(256) pool_kernel(const PoolParams p) {
 
 // Generic fallback, one element per thread: out[map(n,y,x)][c] = a[n,y,x,c] (+ b[n,y,x,c]).
 // map: identity, nearest upsample x2 (layers.py:112-116) or block-major reorg x2 (layers.py:90-97).
-template <typename T>
+template <bool F32>
 __global__ void __launch_bounds__(256) eltwise_kernel(const EltParams p) {
+    typedef typename std::conditional<F32, float, _Float16>::type T;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < p.total; w += stride) {
         const int c = (int)(w % p.C);
@@ -176,8 +180,8 @@ hipError_t launch_resize(const ResizeParams &p, hipStream_t s) {
 }
 
 hipError_t launch_prep(const PrepParams &p, int dtype, hipStream_t s) {
-    if (dtype == YOLO_DTYPE_F16) hipLaunchKernelGGL(prep_kernel<_Float16>, dim3(grid_for(p.pixels)), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(prep_kernel<float>, dim3(grid_for(p.pixels)), dim3(256), 0, s, p);
+    if (dtype == YOLO_DTYPE_F16) hipLaunchKernelGGL(prep_kernel<false>, dim3(grid_for(p.pixels)), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(prep_kernel<true>, dim3(grid_for(p.pixels)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -191,20 +195,28 @@ hipError_t launch_pool(const PoolParams &p0, int dtype, hipStream_t s) {
     p.total = pix * (vec ? p.C / epc : p.C);
     const dim3 g(grid_for(p.total)), b(256);
     if (dtype == YOLO_DTYPE_F16) {
-        if (vec) hipLaunchKernelGGL((pool_kernel<_Float16, true>), g, b, 0, s, p);
-        else hipLaunchKernelGGL((pool_kernel<_Float16, false>), g, b, 0, s, p);
+        if (vec) hipLaunchKernelGGL((pool_kernel<false, true>), g, b, 0, s, p);
+        else hipLaunchKernelGGL((pool_kernel<false, false>), g, b, 0, s, p);
     } else {
-        if (vec) hipLaunchKernelGGL((pool_kernel<float, true>), g, b, 0, s, p);
-        else hipLaunchKernelGGL((pool_kernel<float, false>), g, b, 0, s, p);
+        if (vec) hipLaunchKernelGGL((pool_kernel<true, true>), g, b, 0, s, p);
+        else hipLaunchKernelGGL((pool_kernel<true, false>), g, b, 0, s, p);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_eltwise(const EltParams &p, int dtype, hipStream_t s) {
     const dim3 g(grid_for(p.total)), b(256);
-    if (dtype == YOLO_DTYPE_F16) hipLaunchKernelGGL(eltwise_kernel<_Float16>, g, b, 0, s, p);
-    else hipLaunchKernelGGL(eltwise_kernel<float>, g, b, 0, s, p);
+    if (dtype == YOLO_DTYPE_F16) hipLaunchKernelGGL(eltwise_kernel<false>, g, b, 0, s, p);
+    else hipLaunchKernelGGL(eltwise_kernel<true>, g, b, 0, s, p);
     return hipGetLastError();
+}
+
+// the names rocprofv3's kernel trace prints (yolo_kernel_info.symbol)
+std::string aux_symbol(int kind, int dtype, bool vec) {
+    const char *f = dtype == YOLO_DTYPE_F16 ? "false" : "true";
+    if (kind == K_PREP) return std::string("void yolo::prep_kernel<") + f + ">(yolo::PrepParams)";
+    if (kind == K_POOL) return std::string("void yolo::pool_kernel<") + f + ", " + (vec ? "true" : "false") + ">(yolo::PoolParams)";
+    return std::string("void yolo::eltwise_kernel<") + f + ">(yolo::EltParams)";
 }
 
 }  // namespace yolo

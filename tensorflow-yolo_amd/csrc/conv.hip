@@ -21,14 +21,17 @@
 //   * pipeline: global loads of tile t+1 are issued before the MFMAs of tile t and written to the
 //     other LDS buffer after them; one barrier per K tile.
 #include "conv_common.h"
+#include <type_traits>
 
 namespace yolo {
 
 #define INVALID_OFF YOLO_INVALID_OFF
 
 // WM x WN waves; a wave owns TM*16 couts x TP*16 pixels.
-template <typename T, int WM, int WN, int TM, int TP, bool PERCHUNK>
+// (F32 rather than the element type as template parameter: see conv_tap.hip)
+template <bool F32, int WM, int WN, int TM, int TP, bool PERCHUNK>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
+    typedef typename std::conditional<F32, float, _Float16>::type T;
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int NA = WM * TM * 16;        // couts per block
     constexpr int NB = WN * TP * 16;        // pixels per block
@@ -174,7 +177,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     conv_epilogue<T, TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH, m0 + wn * (TP * 16), fr);
 }
 
-template <typename T, bool PC>
+template <bool F32, bool PC>
 static hipError_t launch_cfg(const ConvParams &p0, int cfg, hipStream_t s) {
     ConvParams p = p0;
     int na, nb;
@@ -191,17 +194,24 @@ static hipError_t launch_cfg(const ConvParams &p0, int cfg, hipStream_t s) {
     conv_set_divisors(p, p.tiles_per_tap);
     dim3 grid((unsigned)blocks), block(256);
     switch (cfg) {
-    case CFG_N128: hipLaunchKernelGGL((conv_igemm_kernel<T, 2, 2, 4, 4, PC>), grid, block, 0, s, p); break;
-    case CFG_N64: hipLaunchKernelGGL((conv_igemm_kernel<T, 1, 4, 4, 4, PC>), grid, block, 0, s, p); break;
-    default: hipLaunchKernelGGL((conv_igemm_kernel<T, 1, 4, 2, 4, PC>), grid, block, 0, s, p); break;
+    case CFG_N128: hipLaunchKernelGGL((conv_igemm_kernel<F32, 2, 2, 4, 4, PC>), grid, block, 0, s, p); break;
+    case CFG_N64: hipLaunchKernelGGL((conv_igemm_kernel<F32, 1, 4, 4, 4, PC>), grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((conv_igemm_kernel<F32, 1, 4, 2, 4, PC>), grid, block, 0, s, p); break;
     }
     return hipGetLastError();
 }
 
 hipError_t launch_conv(const ConvParams &p, int dtype, int cfg, bool perchunk, hipStream_t s) {
     if (dtype == YOLO_DTYPE_F16)
-        return perchunk ? launch_cfg<_Float16, true>(p, cfg, s) : launch_cfg<_Float16, false>(p, cfg, s);
-    return perchunk ? launch_cfg<float, true>(p, cfg, s) : launch_cfg<float, false>(p, cfg, s);
+        return perchunk ? launch_cfg<false, true>(p, cfg, s) : launch_cfg<false, false>(p, cfg, s);
+    return perchunk ? launch_cfg<true, true>(p, cfg, s) : launch_cfg<true, false>(p, cfg, s);
+}
+
+// the name rocprofv3's kernel trace prints (yolo_kernel_info.symbol)
+std::string conv_symbol(int dtype, int cfg, bool perchunk) {
+    const char *shape = cfg == CFG_N128 ? "2, 2, 4, 4" : cfg == CFG_N64 ? "1, 4, 4, 4" : "1, 4, 2, 4";
+    return std::string("void yolo::conv_igemm_kernel<") + (dtype == YOLO_DTYPE_F16 ? "false" : "true") + ", " + shape + ", " +
+           (perchunk ? "true" : "false") + ">(yolo::ConvParams)";
 }
 
 }  // namespace yolo

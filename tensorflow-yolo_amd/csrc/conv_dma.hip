@@ -195,13 +195,20 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
         }
         __builtin_amdgcn_sched_barrier(0);  // no ds_read / MFMA of the previous tile moves below the barrier (see conv_tap.hip)
         __builtin_amdgcn_s_barrier();       // tile kt visible to every wave; stage `fill` no longer read
+#ifdef YOLO_EXPERIMENT      // ablation flags (tools/ablate.py: results intentionally wrong); not in the product build
         if (kt + S - 1 < KT && !(p.dbg & 1)) issue_tile(kt + S - 1, fill);
         if (!(p.dbg & 2)) compute(stage);
+#else
+        if (kt + S - 1 < KT) issue_tile(kt + S - 1, fill);
+        compute(stage);
+#endif
         stage = stage + 1 == S ? 0 : stage + 1;
         fill = fill + 1 == S ? 0 : fill + 1;
     }
 
+#ifdef YOLO_EXPERIMENT
     if (p.dbg & 4) return;             // experiment: no epilogue
+#endif
     if (p.out_f32 && !p.vec_out && p.outmode == OUT_NORMAL && !p.has_res) {      // head conv: coalesced float32 rows via LDS
         static_assert(8 * 16 * kStagePitch(TM) * 4 <= S * TILE_BYTES, "staging slabs must fit in the ring");
         __syncthreads();            // every wave is done reading the ring
@@ -282,9 +289,11 @@ static const TileCost kCost[] = {
 
 int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W, bool tap_only) {
     const int ksize = taps == 9 ? 3 : 1;
+#ifdef YOLO_EXPERIMENT      // tools/gpu_tile_sweep.sh: force one tile id on every layer that accepts it
     const char *force = getenv("YOLO_CONV_TILE");
     if (force && *force && dma_cfg_valid(atoi(force), cout, cin_chunks, v1_ok, ksize, stride, W) && (!tap_only || atoi(force) == 0 || is_tap_cfg(atoi(force))))
         return atoi(force);
+#endif
     const int fallback = v1_ok ? 0 : -1;
     if (cout <= 64) {   // narrow, bandwidth-bound layers: 3x3/1 with tap reuse (304x304 32->64: 239 us vs 273 on the 64x512 tile)
         if (M >= 8192 && dma_cfg_valid(13, cout, cin_chunks, v1_ok, ksize, stride, W)) return 13;
@@ -332,11 +341,24 @@ int dma_cfg_na(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg].na : 128
 int dma_cfg_bkc(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg].bkc : 8; }
 const char *dma_cfg_name(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg].name : ""; }
 
+// tile id, then the template arguments WM, WN, TM, TP, S, BKC, OCC (", "-separated: the stringified list equals the demangled symbol)
+#define YOLO_DMA_VARIANTS(X) \
+    X(1, 2, 4, 8, 4, 2, 8, 2) \
+    X(2, 4, 2, 4, 4, 3, 8, 2) \
+    X(3, 2, 4, 4, 4, 3, 8, 2) \
+    X(4, 2, 4, 8, 4, 4, 4, 2) \
+    X(5, 4, 2, 4, 4, 3, 4, 4) \
+    X(6, 2, 4, 4, 4, 3, 4, 4) \
+    X(7, 1, 8, 4, 4, 2, 4, 4) \
+    X(14, 2, 4, 4, 2, 3, 4, 6)
+
 hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
     if (cfg <= 0 || cfg >= kNumCfgs) return hipErrorInvalidValue;
     ConvParams p = p0;
     const DmaCfg &k = kCfgs[cfg];
+#ifdef YOLO_EXPERIMENT
     { const char *d = getenv("YOLO_CONV_DBG"); p.dbg = d ? atoi(d) : 0; }
+#endif
     p.n_tiles_n = (p.Cout + k.na - 1) / k.na;
     const long long blocks = ((long long)p.M + k.nb - 1) / k.nb * p.n_tiles_n;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -360,6 +382,7 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
         conv_set_divisors(p, p.cin_chunks / k.bkc);
         // experiment: YOLO_CONV_TRACE=<file> appends, for every tap-reuse launch, a header {blocks, M, Cout, cin_chunks,
         // H, W, cfg, 0} and 8 uint64 per block (see the kernel); synchronous, for tools/trace_blocks.py only
+#ifdef YOLO_EXPERIMENT
         if (const char *tf = getenv("YOLO_CONV_TRACE")) {
             unsigned long long *dev = nullptr;
             const size_t bytes = (size_t)p.n_blocks * 64;
@@ -382,21 +405,28 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
             }
             return e;
         }
+#endif
         return launch_conv_tap(p, cfg - kFirstTapCfg, s);
     }
     const dim3 grid((unsigned)blocks), block(512);
     switch (cfg) {
-    case 1: hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 8, 4, 2, 8, 2>), grid, block, 0, s, p); break;
-    case 2: hipLaunchKernelGGL((conv_igemm_dma_kernel<4, 2, 4, 4, 3, 8, 2>), grid, block, 0, s, p); break;
-    case 3: hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 4, 4, 3, 8, 2>), grid, block, 0, s, p); break;
-    case 4: hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 8, 4, 4, 4, 2>), grid, block, 0, s, p); break;
-    case 5: hipLaunchKernelGGL((conv_igemm_dma_kernel<4, 2, 4, 4, 3, 4, 4>), grid, block, 0, s, p); break;
-    case 6: hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 4, 4, 3, 4, 4>), grid, block, 0, s, p); break;
-    case 7: hipLaunchKernelGGL((conv_igemm_dma_kernel<1, 8, 4, 4, 2, 4, 4>), grid, block, 0, s, p); break;
-    case 14: hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 4, 2, 3, 4, 6>), grid, block, 0, s, p); break;
+#define X(id, ...) case id: hipLaunchKernelGGL((conv_igemm_dma_kernel<__VA_ARGS__>), grid, block, 0, s, p); break;
+        YOLO_DMA_VARIANTS(X)
+#undef X
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+// the name rocprofv3's kernel trace prints for the kernel a tile id runs (yolo_kernel_info.symbol)
+const char *dma_cfg_symbol(int cfg, bool f32) {
+    if (is_tap_cfg(cfg)) return conv_tap_symbol(cfg - kFirstTapCfg, f32);
+    switch (cfg) {
+#define X(id, ...) case id: return "void yolo::conv_igemm_dma_kernel<" #__VA_ARGS__ ">(yolo::ConvParams)";
+        YOLO_DMA_VARIANTS(X)
+#undef X
+    default: return "";
+    }
 }
 
 }  // namespace yolo

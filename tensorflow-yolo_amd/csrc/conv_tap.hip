@@ -59,8 +59,11 @@ __device__ __forceinline__ int tap_swz_w(int r) { return (0x78 >> (2 * ((r >> 2)
 // immediates), tap shift kh * 24 + kw; pixels of partial tiles outside the image are computed and dropped.
 // T = _Float16 (32-channel slices, mfma_f32_16x16x32_f16) or float (16-channel slices, four mfma_f32_16x16x4f32 per
 // fragment pair: the exact fp32 FMA chain of conv.hip) -- the LDS geometry is in 16-byte chunks either way.
-template <typename T, int WM, int WN, int TM, int TP, int PRG, int OCC, int MODE = 1>
+// (F32 instead of the element type as template parameter: rocprofv3 does not demangle `_Float16` template arguments, and
+// yolo_kernel_info.symbol must be the name its kernel trace prints)
+template <bool F32, int WM, int WN, int TM, int TP, int PRG, int OCC, int MODE>
 __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams p) {
+    typedef typename std::conditional<F32, float, _Float16>::type T;
     constexpr int NW = 8;
     constexpr int S = 3;                    // weight ring slots (9 taps per slice: slot = tap % 3)
     constexpr int ROWB = 64;
@@ -81,8 +84,10 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     unsigned char *const smemP = smem + S * A_BYTES;
 
     const int tid = threadIdx.x;
+#ifdef YOLO_EXPERIMENT      // block trace (tools/trace_blocks.py); not in the product build
     const unsigned long long t_start = p.trace ? wall_clock64() : 0ull;
     const unsigned long long c_start = p.trace ? (unsigned long long)clock64() : 0ull;
+#endif
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -188,7 +193,9 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     };
 
     // ---- prologue: patch of slice 0, weights of taps 0 and 1 --------------------------------------
+#ifdef YOLO_EXPERIMENT
     const unsigned long long t_setup = p.trace ? wall_clock64() : 0ull;
+#endif
     issue_patch(0, 0);
     issue_weights(0, 0, 0);
     issue_weights(1, 0, 1);
@@ -234,8 +241,11 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         if (c + 1 < C) run_slice(c + 1, std::integral_constant<int, 1>());
     }
     (void)KT;
+#ifdef YOLO_EXPERIMENT
     const unsigned long long t_loop = p.trace ? wall_clock64() : 0ull;
+#endif
     conv_epilogue<T, TM, TP, MODE>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
+#ifdef YOLO_EXPERIMENT
     if (p.trace && tid == 0) {          // YOLO_CONV_TRACE: phase timestamps (100 MHz) + placement of wave 0 of every block
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned long long *r = p.trace + (size_t)blockIdx.x * 8;
@@ -245,6 +255,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         r[6] = (unsigned long long)bid;
         r[7] = (unsigned long long)clock64() - c_start;     // shader-clock cycles of the block (vs r[3] - r[0] at 100 MHz)
     }
+#endif
 }
 
 // variants: 0 = 128 couts x 256 positions, 1 = 256 x 256 (one workgroup per CU), 2 = 128 x 192, 3 = 128 x 128 (smaller
@@ -259,29 +270,37 @@ bool conv_tap_fits(int variant, int W) {
     return kTapNB[variant] + 2 * W + 4 <= kTapPRG[variant] * 16;
 }
 
+// variant id, then the template arguments after F32: WM, WN, TM, TP, PRG, OCC, MODE (written with ", " so that the
+// stringified list equals the demangled symbol)
+#define YOLO_TAP_VARIANTS(X) \
+    X(0, 2, 4, 4, 4, 26, 4, 1) \
+    X(1, 2, 4, 8, 4, 26, 2, 1) \
+    X(2, 2, 4, 4, 3, 26, 4, 1) \
+    X(3, 2, 4, 4, 2, 28, 4, 1) \
+    X(4, 2, 4, 4, 4, 27, 4, 2) \
+    X(5, 1, 8, 4, 2, 27, 4, 2)
+
+const char *conv_tap_symbol(int variant, bool f32) {
+    switch (variant) {
+#define X(id, ...) case id: return f32 ? "void yolo::conv3x3_tap_kernel<true, " #__VA_ARGS__ ">(yolo::ConvParams)" \
+                                       : "void yolo::conv3x3_tap_kernel<false, " #__VA_ARGS__ ">(yolo::ConvParams)";
+        YOLO_TAP_VARIANTS(X)
+#undef X
+    default: return "";
+    }
+}
+
 hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
     if (p.ksize != 3 || p.stride != 1 || p.pad != 1 || p.Ho != p.H || p.Wo != p.W || (p.cin_chunks & 3) || !conv_tap_fits(variant, p.W))
         return hipErrorInvalidValue;
     const dim3 grid((unsigned)p.n_blocks);
-    if (p.f32) {
-        switch (variant) {
-        case 0: hipLaunchKernelGGL((conv3x3_tap_kernel<float, 2, 4, 4, 4, 26, 4>), grid, dim3(512), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((conv3x3_tap_kernel<float, 2, 4, 8, 4, 26, 2>), grid, dim3(512), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((conv3x3_tap_kernel<float, 2, 4, 4, 3, 26, 4>), grid, dim3(512), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((conv3x3_tap_kernel<float, 2, 4, 4, 2, 28, 4>), grid, dim3(512), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((conv3x3_tap_kernel<float, 2, 4, 4, 4, 27, 4, 2>), grid, dim3(512), 0, s, p); break;
-        case 5: hipLaunchKernelGGL((conv3x3_tap_kernel<float, 1, 8, 4, 2, 27, 4, 2>), grid, dim3(512), 0, s, p); break;
-        default: return hipErrorInvalidValue;
-        }
-        return hipGetLastError();
-    }
     switch (variant) {
-    case 0: hipLaunchKernelGGL((conv3x3_tap_kernel<_Float16, 2, 4, 4, 4, 26, 4>), grid, dim3(512), 0, s, p); break;
-    case 1: hipLaunchKernelGGL((conv3x3_tap_kernel<_Float16, 2, 4, 8, 4, 26, 2>), grid, dim3(512), 0, s, p); break;
-    case 2: hipLaunchKernelGGL((conv3x3_tap_kernel<_Float16, 2, 4, 4, 3, 26, 4>), grid, dim3(512), 0, s, p); break;
-    case 3: hipLaunchKernelGGL((conv3x3_tap_kernel<_Float16, 2, 4, 4, 2, 28, 4>), grid, dim3(512), 0, s, p); break;
-    case 4: hipLaunchKernelGGL((conv3x3_tap_kernel<_Float16, 2, 4, 4, 4, 27, 4, 2>), grid, dim3(512), 0, s, p); break;
-    case 5: hipLaunchKernelGGL((conv3x3_tap_kernel<_Float16, 1, 8, 4, 2, 27, 4, 2>), grid, dim3(512), 0, s, p); break;
+#define X(id, ...) case id: \
+        if (p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<true, __VA_ARGS__>), grid, dim3(512), 0, s, p); \
+        else hipLaunchKernelGGL((conv3x3_tap_kernel<false, __VA_ARGS__>), grid, dim3(512), 0, s, p); \
+        break;
+        YOLO_TAP_VARIANTS(X)
+#undef X
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

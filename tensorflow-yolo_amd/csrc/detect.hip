@@ -9,6 +9,8 @@
 //                 list.sort(key=prob, reverse=True) over the scan-ordered list (base.py:199),
 //                 then suppressed greedily; IoU in float64 exactly as base.py:180-192 computes it
 //                 (x,y float32; w,h float64; union floored at 1e-8; suppress when iou >= thr).
+#include <atomic>
+
 #include "yolo_internal.h"
 
 namespace yolo {
@@ -107,10 +109,15 @@ __host__ __device__ inline size_t nms_union_bytes(size_t cap2) {
 // Up to 4096 candidates per image it lives in LDS (dynamic); above (GLOBAL: up to 65536, e.g. a mAP-style
 // threshold of 0.005 on 22 743 rows) the same algorithm runs on a per-image slab of global memory that stays in L2
 // (one workgroup per image either way: __syncthreads orders the slab accesses inside the CU).
+// An image with at most 512 candidates (the usual case) takes the single-wave path, whose working set (carved for a
+// capacity of 512: 51 KiB) always lives in LDS -- in the GLOBAL instantiation too, where the single-wave sort would
+// otherwise exchange keys between lanes through global memory with nothing but in-order L1 behaviour to order them.
 extern __shared__ __attribute__((aligned(16))) unsigned char nms_dyn_lds[];
+constexpr int kNmsSmall = 512;
+constexpr size_t kNmsSmallLds = 1024 + 49152 + 1024 + 64;        // idx | union | kept for cap2 = 512 (nms_lds_bytes(512))
 template <bool GLOBAL>
 __global__ void __launch_bounds__(1024) nms_kernel(const NmsParams p) {
-    unsigned char *lds = GLOBAL ? p.scratch + (size_t)blockIdx.x * p.scratch_stride : nms_dyn_lds;
+    __shared__ __attribute__((aligned(16))) unsigned char small_lds[GLOBAL ? kNmsSmallLds : 16];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     int nthr = blockDim.x;
@@ -122,11 +129,12 @@ __global__ void __launch_bounds__(1024) nms_kernel(const NmsParams p) {
         if (tid == 0) { p.counts[b] = 0; p.status[b] = status; }
         return;
     }
-    const bool small = n <= 512;        // the usual case: single-wave sort + suppression bit matrix + single-wave greedy pass
+    const bool small = n <= kNmsSmall;  // the usual case: single-wave sort + suppression bit matrix + single-wave greedy pass
+    unsigned char *lds = !GLOBAL ? nms_dyn_lds : small ? small_lds : p.scratch + (size_t)blockIdx.x * p.scratch_stride;
     int n2 = 2;
     while (n2 < n) n2 <<= 1;
     int cap2 = 2;
-    while (cap2 < p.cap) cap2 <<= 1;
+    while (cap2 < ((GLOBAL && small) ? kNmsSmall : p.cap)) cap2 <<= 1;
 
     unsigned short *idx = reinterpret_cast<unsigned short *>(lds);
     unsigned char *u = lds + (((size_t)cap2 * 2 + 15) & ~(size_t)15);
@@ -317,11 +325,14 @@ hipError_t launch_nms(const NmsParams &p, int batch, hipStream_t s) {
         hipLaunchKernelGGL(nms_kernel<true>, dim3((unsigned)batch), dim3(1024), 0, s, p);
         return hipGetLastError();
     }
-    static size_t configured = 0;
-    if (lds > configured) {
+    // the dynamic-LDS limit is a per-device property of the function: remember what was set per device ordinal
+    static std::atomic<size_t> configured[64];
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    if (dev < 0 || dev >= 64 || lds > configured[dev].load(std::memory_order_relaxed)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(nms_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        configured = lds;
+        if (dev >= 0 && dev < 64) configured[dev].store(lds, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(nms_kernel<false>, dim3((unsigned)batch), dim3(1024), lds, s, p);
     return hipGetLastError();

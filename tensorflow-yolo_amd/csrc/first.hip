@@ -9,6 +9,7 @@
 // fp16 nets: input and weights are rounded to fp16 first (same operands as the MFMA path), products
 // accumulate in fp32.
 #include "yolo_internal.h"
+#include <type_traits>
 
 namespace yolo {
 
@@ -18,8 +19,9 @@ typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 // registers: a wave covers 32 x-positions of two adjacent rows (lane = 32 * row + x), the 2x2 window is a max over
 // lanes l ^ 1 and l ^ 32 of the raw accumulators (bias and leaky are monotone: pooling first is the same result with
 // a quarter of the activation work), and only the pooled pixel row (16 per wave) is written.  H and W even.
-template <typename T, int COUT, bool POOL>
+template <bool F32, int COUT, bool POOL>
 __global__ void __launch_bounds__(256) conv_first_kernel(const FirstParams p) {
+    typedef typename std::conditional<F32, float, _Float16>::type T;
     constexpr int EPC = 16 / (int)sizeof(T);
     constexpr int ROWB = COUT * (int)sizeof(T);     // bytes of one output pixel
     constexpr int NCH = ROWB / 16;                  // 16-byte chunks per pixel
@@ -151,7 +153,7 @@ __global__ void __launch_bounds__(256) conv_first_kernel(const FirstParams p) {
     }
 }
 
-template <typename T, int COUT>
+template <bool T, int COUT>
 static void launch_first_t(const FirstParams &p, dim3 grid, hipStream_t s) {
     if (p.pool) hipLaunchKernelGGL((conv_first_kernel<T, COUT, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv_first_kernel<T, COUT, false>), grid, dim3(256), 0, s, p);
@@ -174,15 +176,20 @@ hipError_t launch_first(const FirstParams &p0, int dtype, hipStream_t s) {
     }
     const dim3 grid((unsigned)g);
     if (dtype == YOLO_DTYPE_F16) {
-        if (p.Cout == 32) launch_first_t<_Float16, 32>(p, grid, s);
-        else if (p.Cout == 16) launch_first_t<_Float16, 16>(p, grid, s);
+        if (p.Cout == 32) launch_first_t<false, 32>(p, grid, s);
+        else if (p.Cout == 16) launch_first_t<false, 16>(p, grid, s);
         else return hipErrorInvalidValue;
     } else {
-        if (p.Cout == 32) launch_first_t<float, 32>(p, grid, s);
-        else if (p.Cout == 16) launch_first_t<float, 16>(p, grid, s);
+        if (p.Cout == 32) launch_first_t<true, 32>(p, grid, s);
+        else if (p.Cout == 16) launch_first_t<true, 16>(p, grid, s);
         else return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+std::string first_symbol(int dtype, int cout, bool pool) {
+    return std::string("void yolo::conv_first_kernel<") + (dtype == YOLO_DTYPE_F16 ? "false" : "true") + ", " + std::to_string(cout) + ", " +
+           (pool ? "true" : "false") + ">(yolo::FirstParams)";
 }
 
 }  // namespace yolo

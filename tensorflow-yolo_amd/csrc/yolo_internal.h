@@ -218,6 +218,12 @@ hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s);    
 bool conv_tap_fits(int variant, int W);
 bool conv_tap_is2d(int variant);
 const char *dma_cfg_name(int cfg);
+// names exactly as rocprofv3's kernel trace prints them (yolo_kernel_info.symbol: joins bench.py's roofline to profiles/*.csv)
+const char *dma_cfg_symbol(int cfg, bool f32);
+const char *conv_tap_symbol(int variant, bool f32);
+std::string conv_symbol(int dtype, int cfg, bool perchunk);
+std::string first_symbol(int dtype, int cout, bool pool);
+std::string aux_symbol(int kind, int dtype, bool vec);
 int dma_num_cfgs();
 int dma_cfg_na(int cfg);
 hipError_t launch_prep(const PrepParams &p, int dtype, hipStream_t s);

@@ -10,6 +10,7 @@ import ctypes as C
 import numpy as np
 
 from .. import _hip
+from . import dist as ydist
 from . import layers as L
 
 
@@ -71,7 +72,8 @@ class Plan(object):
     """Device-free part: create the native net object, query sizes, print the plan.
     Works without a GPU (used by the CPU test-suite to check planning)."""
 
-    def __init__(self, net, dtype="fp16", max_batch=1, keep_all=False, cand_capacity=4096, max_boxes=256, streams=0):
+    def __init__(self, net, dtype="fp16", max_batch=1, keep_all=False, cand_capacity=4096, max_boxes=_hip.DEFAULT_MAX_BOXES, streams=0,
+                 force_tile=None):
         self.lib = _hip.lib()
         self.layers = list(net)
         known = {"fp16": _hip.DTYPE_F16, "f16": _hip.DTYPE_F16, "half": _hip.DTYPE_F16,
@@ -83,7 +85,8 @@ class Plan(object):
         self.max_boxes = int(max_boxes)
         self.cand_capacity = int(cand_capacity)
         opt = _hip.NetOptions(dtype=self.dtype, max_batch=self.max_batch, keep_all=int(bool(keep_all)),
-                              cand_capacity=self.cand_capacity, max_boxes=self.max_boxes, streams=int(streams))
+                              cand_capacity=self.cand_capacity, max_boxes=self.max_boxes, streams=int(streams),
+                              force_tile=0 if force_tile is None else int(force_tile) + 1)
         descs = to_descs(self.layers)
         handle = C.c_void_p()
         _hip.check(self.lib.yolo_net_create(descs, len(self.layers), C.byref(opt), C.byref(handle)), "yolo_net_create")
@@ -135,8 +138,9 @@ class HipNetwork(Plan):
         with torch.cuda.device(self.device):
             self._weights = torch.empty(max(self.weights_bytes, 256), dtype=torch.uint8, device=self.device)
             self._workspace = torch.zeros(max(self.workspace_bytes, 256), dtype=torch.uint8, device=self.device)
-            self._boxes = torch.empty((self.max_batch, self.max_boxes, 6), dtype=torch.float32, device=self.device)
-            self._counts = torch.zeros((2, self.max_batch), dtype=torch.int32, device=self.device)
+            # ONE record buffer [counts | status | boxes] (net/dist.py): what a multi-GPU run all-gathers as it is
+            self.records = torch.zeros(ydist.record_words(self.max_batch, self.max_boxes), dtype=torch.int32, device=self.device)
+            self._boxes, self._counts, self._status = ydist.split_records(self.records, self.max_batch, self.max_boxes)
             _hip.check(self.lib.yolo_net_bind_workspace(self.handle, self._workspace.data_ptr(), self._workspace.numel()),
                        "yolo_net_bind_workspace")
         self.weights_loaded = False
@@ -191,9 +195,9 @@ class HipNetwork(Plan):
         b = x.shape[0]
         with torch.cuda.device(self.device):
             _hip.check(self.lib.yolo_net_detect(self.handle, x.data_ptr(), b, float(threshold), float(iou_threshold),
-                                                int(nms_mode), self._boxes.data_ptr(), self._counts[0].data_ptr(),
-                                                self._counts[1].data_ptr(), self._stream()), "yolo_net_detect")
-        return self._boxes[:b], self._counts[0, :b], self._counts[1, :b]
+                                                int(nms_mode), self._boxes.data_ptr(), self._counts.data_ptr(),
+                                                self._status.data_ptr(), self._stream()), "yolo_net_detect")
+        return self._boxes[:b], self._counts[:b], self._status[:b]
 
     def autotune(self, x):
         """Pick the fastest conv tile per layer by timing them on the device (optional, synchronous)."""
@@ -230,15 +234,26 @@ class HipNetwork(Plan):
         return host
 
 
-def records_to_host(boxes, counts, status):
-    """Device records -> per-image list of (x, y, w, h, class_idx, prob) tuples (synchronises).
-    Raises if the candidate list overflowed (the result would not be the reference's)."""
-    boxes = boxes.cpu().numpy()
-    counts = counts.cpu().numpy()
-    status = status.cpu().numpy()
+def check_status(status, allow_truncation=False):
+    """The reference's lists are unbounded (net/base.py:195-209); the record buffers are not.  Both overflow bits mean the
+    result would differ from the reference's, so both raise: bit 0 = more candidates than cand_capacity passed the
+    threshold, bit 1 = more NMS survivors than max_boxes."""
+    status = np.asarray(status).reshape(-1)
     if (status & 1).any():
         raise _hip.YoloHipError("candidate capacity exceeded for image(s) %s: raise cand_capacity or the threshold"
                                 % np.nonzero(status & 1)[0].tolist())
+    if (status & 2).any() and not allow_truncation:
+        raise _hip.YoloHipError("more than max_boxes boxes survive NMS for image(s) %s: the list would be truncated "
+                                "(the reference has no cap): raise max_boxes" % np.nonzero(status & 2)[0].tolist())
+
+
+def records_to_host(boxes, counts, status, allow_truncation=False):
+    """Device records -> per-image list of (x, y, w, h, class_idx, prob) tuples (synchronises).
+    Raises if a capacity was exceeded (the result would not be the reference's): check_status."""
+    boxes = boxes.cpu().numpy()
+    counts = counts.cpu().numpy()
+    status = status.cpu().numpy()
+    check_status(status, allow_truncation)
     out = []
     cls = boxes[..., 5].view(np.int32)
     for i in range(boxes.shape[0]):
@@ -248,7 +263,8 @@ def records_to_host(boxes, counts, status):
     return out, status
 
 
-def decode_nms(head, logits, threshold, iou_threshold, nms_mode=_hip.NMS_AGNOSTIC, cand_capacity=4096, max_boxes=256):
+def decode_nms(head, logits, threshold, iou_threshold, nms_mode=_hip.NMS_AGNOSTIC, cand_capacity=4096,
+               max_boxes=_hip.DEFAULT_MAX_BOXES, allow_truncation=False):
     """Standalone decode + NMS of a head tensor already on (or copied to) the device:
     the drop-in for find_bounding_boxes (reference net/v2.py:83-90, net/v3.py:140-151)."""
     torch = _torch()
@@ -267,4 +283,4 @@ def decode_nms(head, logits, threshold, iou_threshold, nms_mode=_hip.NMS_AGNOSTI
                                        int(nms_mode), cand_capacity, max_boxes, scratch.data_ptr(), nbytes,
                                        boxes.data_ptr(), counts[0].data_ptr(), counts[1].data_ptr(),
                                        torch.cuda.current_stream(dev).cuda_stream), "yolo_decode_nms")
-        return records_to_host(boxes, counts[0], counts[1])
+        return records_to_host(boxes, counts[0], counts[1], allow_truncation)

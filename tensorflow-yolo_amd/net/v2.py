@@ -12,6 +12,7 @@ are out of scope for this inference backend.
 """
 import numpy as np
 
+from .. import _hip
 from . import base, engine
 from .layers import conv2d_bn_act, input_layer, max_pool2d, reorg, route
 from .v3 import Network as _Network, attach_weights
@@ -100,5 +101,5 @@ def find_bounding_boxes(net_out, net, threshold, iou_threshold, anchors, class_n
     eng = getattr(net, "engine", None)
     records, _ = engine.decode_nms(head, net_out, threshold, iou_threshold, nms_mode,
                                    cand_capacity=eng.cand_capacity if eng else 4096,
-                                   max_boxes=eng.max_boxes if eng else 1024)
+                                   max_boxes=eng.max_boxes if eng else _hip.DEFAULT_MAX_BOXES)
     return base.boxes_from_records(records)

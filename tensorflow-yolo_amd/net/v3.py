@@ -7,6 +7,7 @@ weight order carry over.
 """
 import numpy as np
 
+from .. import _hip
 from . import base, engine
 from .layers import conv2d_bn_act, detection_layer, input_layer, route, shortcut, upsample, yolo_layer
 
@@ -98,5 +99,5 @@ def find_bounding_boxes(net_out, net, threshold, iou_threshold, anchors, class_n
     eng = getattr(net, "engine", None)
     records, _ = engine.decode_nms(head, net_out, threshold, iou_threshold, nms_mode,
                                    cand_capacity=eng.cand_capacity if eng else 4096,
-                                   max_boxes=eng.max_boxes if eng else 256)
+                                   max_boxes=eng.max_boxes if eng else _hip.DEFAULT_MAX_BOXES)
     return base.boxes_from_records(records)

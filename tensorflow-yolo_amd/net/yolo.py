@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 from .. import _hip
-from . import base, engine, v2, v3
+from . import base, dist as ydist, engine, v2, v3
 
 
 class Yolo(object):
@@ -22,6 +22,7 @@ class Yolo(object):
     def __init__(self):
         self.net = None
         self.params = None
+        self.last_status = None
 
     # ---- out of scope for an inference backend ------------------------------------------------
     def train(self, params):
@@ -57,15 +58,35 @@ class Yolo(object):
         self.net = net
         return net
 
-    def predict(self, x_batch, threshold=0.5, iou_threshold=0.6, nms_mode=_hip.NMS_AGNOSTIC):
+    def predict(self, x_batch, threshold=0.5, iou_threshold=0.6, nms_mode=_hip.NMS_AGNOSTIC, group=None):
         """One batch: forward + decode + NMS on the GPU (the body of the reference's test loop,
         net/yolo.py:83-86).  x_batch: [B,H,W,C] in [0,1], RGB (NumPy or torch).
-        Returns list[B] of list[BoundingBox], each in descending-prob (stable) order."""
+        Returns list[B] of list[BoundingBox], each in descending-prob (stable) order.
+
+        Under an initialised `torch.distributed` group of W > 1 ranks (one process per GPU) every rank passes the SAME
+        global batch: rank r runs images shard_range(B, r, W), the fixed-size box records are all-gathered (the only
+        exchange, net/dist.py) and every rank returns the full list.  `self.last_status` keeps the per-image status
+        words (bit 0 candidate overflow, bit 1 more survivors than max_boxes): both raise, the reference has no caps."""
         eng = self.net.engine
         if not eng.weights_loaded:
             raise RuntimeError("no weights loaded: call load_weights / build(weights=...) first")
+        rank, world = ydist.world(group)
+        if world > 1:
+            n = len(x_batch)
+            per = -(-n // world)
+            if per > eng.max_batch:
+                raise ValueError("global batch %d over %d ranks needs max_batch >= %d (engine has %d)" % (n, world, per, eng.max_batch))
+            lo, hi = ydist.shard_range(n, rank, world)
+            boxes, counts, status = ydist.detect_sharded(eng, x_batch[lo:hi] if hi > lo else None, threshold, iou_threshold,
+                                                         nms_mode, group)
+            keep = [r * eng.max_batch + i for r in range(world) for i in range(per)][:n]     # slot of global image g
+            status = status.cpu().numpy().reshape(-1)[keep]
+            self.last_status = status
+            engine.check_status(status)
+            lists = ydist.records_to_lists(boxes, counts)
+            return base.boxes_from_records([lists[k] for k in keep])
         boxes, counts, status = eng.detect(x_batch, threshold, iou_threshold, nms_mode)
-        records, _ = engine.records_to_host(boxes, counts, status)
+        records, self.last_status = engine.records_to_host(boxes, counts, status)
         return base.boxes_from_records(records)
 
     def forward(self, x_batch):
@@ -95,7 +116,10 @@ class Yolo(object):
         if cpu_only:
             print("cpu_only = True is ignored: this backend runs on the MI355X only")
 
-        self.build(anchors, class_names, input_shape, dtype=dtype, max_batch=batch_size)
+        # one process per GPU (torch.distributed initialised by the launcher, e.g. torchrun): every batch of `batch_size`
+        # images shards over the ranks, the box records are all-gathered, rank 0 draws and writes (net/dist.py)
+        rank, world = ydist.world()
+        self.build(anchors, class_names, input_shape, dtype=dtype, max_batch=-(-batch_size // world))
         # TF checkpoints cannot be read without TensorFlow; same fallback order as the reference,
         # whose restore failure falls through to the Darknet weights (net/base.py:55-61, net/yolo.py:72-78)
         if checkpoint_path:
@@ -108,6 +132,8 @@ class Yolo(object):
         batches = base.generate_test_batch if str(params.get("preprocess", "gpu")).lower() == "pillow" else base.generate_test_batch_gpu
         for x_batch, paths in batches(image_paths, batch_size, input_shape):
             net_boxes = self.predict(x_batch, threshold, iou_threshold, nms_mode)
+            if rank != 0:
+                continue
             for boxes, path in zip(net_boxes, paths):
                 new_img = base.draw_boxes(path, boxes, class_names)
                 file_name, file_ext = os.path.splitext(os.path.basename(path))

@@ -1,6 +1,11 @@
-"""CPU: the N>1 path (shard images over ranks, all-gather the box records) with world_size 2 on gloo."""
+"""CPU: the N>1 path with world_size 2 on gloo -- images shard over ranks, ONE all-gather of the fixed-size
+record buffer.  The ranks run the very functions the GPU path runs (`net/dist.py: detect_sharded`, which is
+`bench.py`'s step, and `Yolo.predict`'s sharded branch) on CPU tensors; only the engine is a stand-in that
+fills the record buffer from the input instead of launching kernels (no oracle involved: this is plumbing)."""
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import torch
@@ -8,6 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from helpers import ROOT  # noqa: F401
+from tensorflow_yolo_amd import YoloV3
 from tensorflow_yolo_amd.net import dist as ydist
 
 
@@ -19,6 +25,45 @@ def test_shard_range_covers_batch_in_rank_order():
     assert ydist.shard_range(256, 3, 8) == (96, 128)
 
 
+def test_record_buffer_layout_is_one_contiguous_block():
+    B, K = 3, 5
+    flat = torch.arange(ydist.record_words(B, K), dtype=torch.int32)
+    boxes, counts, status = ydist.split_records(flat, B, K)
+    assert counts.tolist() == [0, 1, 2] and status.tolist() == [3, 4, 5]
+    assert boxes.shape == (B, K, 6) and boxes.dtype == torch.float32
+    assert boxes.data_ptr() == flat.data_ptr() + 4 * 2 * B                 # views, no copies
+    assert boxes.view(torch.int32).reshape(-1).tolist() == list(range(2 * B, ydist.record_words(B, K)))
+
+
+class StandInEngine(object):
+    """What detect_sharded needs from net/engine.py: HipNetwork, on CPU tensors: `.records`, `.max_batch`, `.max_boxes`,
+    `.detect()`.  Image i with mean value m yields round(m * 8) boxes whose fields encode (image tag, k)."""
+    weights_loaded = True
+
+    def __init__(self, max_batch, max_boxes):
+        self.max_batch, self.max_boxes = max_batch, max_boxes
+        self.records = torch.full((ydist.record_words(max_batch, max_boxes),), 12345, dtype=torch.int32)   # stale garbage
+        self._boxes, self._counts, self._status = ydist.split_records(self.records, max_batch, max_boxes)
+        self.calls = 0
+
+    def detect(self, x, threshold, iou_threshold, nms_mode=0):
+        self.calls += 1
+        b = x.shape[0]
+        for i in range(b):
+            tag = float(x[i].mean())
+            n = int(round(tag * 8))
+            self._counts[i] = n
+            self._status[i] = 0
+            for k in range(n):
+                self._boxes[i, k, :5] = torch.tensor([tag, k, 0.5, 0.25, 1.0 - 0.01 * k])
+                self._boxes[i, k, 5:] = torch.tensor([k + 7], dtype=torch.int32).view(torch.float32)
+        return self._boxes[:b], self._counts[:b], self._status[:b]
+
+
+def _expected(tags):
+    return [[(np.float32(t), float(k), 0.5, 0.25, k + 7, float(np.float32(1.0 - 0.01 * k))) for k in range(int(round(t * 8)))] for t in tags]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -27,24 +72,35 @@ def _free_port():
     return p
 
 
+TAGS = [0.125, 0.375, 0.0, 0.625, 0.25]       # global batch of 5 images over 2 ranks: shards of 3 and 2 (one padded slot)
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        B, K = 3, 5
-        rng = np.random.RandomState(100 + rank)
-        boxes = torch.from_numpy(rng.rand(B, K, 6).astype(np.float32))
-        boxes[..., 5] = torch.from_numpy(rng.randint(0, 80, (B, K)).astype(np.int32)).view(torch.float32)
-        counts = torch.tensor([rank + 1, 0, K], dtype=torch.int32)
-        status = torch.zeros(B, dtype=torch.int32)
-        gb, gc, gs = ydist.gather_records(boxes, counts, status)
-        q.put((rank, gb.numpy().copy(), gc.numpy().copy(), boxes.numpy().copy()))
+        x = torch.stack([torch.full((4, 4, 3), t) for t in TAGS])
+        eng = StandInEngine(max_batch=3, max_boxes=6)
+        # (1) the bench step: detect on the local shard + the one all-gather
+        lo, hi = ydist.shard_range(len(TAGS), rank, world)
+        boxes, counts, status = ydist.detect_sharded(eng, x[lo:hi], 0.5, 0.6)
+        lists = ydist.records_to_lists(boxes, counts)
+        # (2) the product API: every rank passes the global batch, gets the global result
+        model = YoloV3()
+        model.net = type("Net", (list,), {})()
+        model.net.engine = eng
+        got = model.predict(x, 0.5, 0.6)
+        # (3) a global batch smaller than the world: rank 1 has no image and still takes part in the exchange
+        got1 = model.predict(x[:1], 0.5, 0.6)
+        q.put((rank, tuple(boxes.shape), counts.tolist(), status.tolist(), lists,
+               [[(b.x, b.y, b.w, b.h, b.class_idx, b.prob) for b in img] for img in got],
+               [[(b.x, b.y, b.w, b.h, b.class_idx, b.prob) for b in img] for img in got1], eng.calls))
     finally:
         dist.destroy_process_group()
 
 
-def test_gather_records_world2_gloo():
+def test_sharded_step_world2_gloo():
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -52,20 +108,41 @@ def test_gather_records_world2_gloo():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    got = sorted((q.get(timeout=60) for _ in range(world)), key=lambda t: t[0])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    local = [g[3] for g in got]
-    for rank, gb, gc, _ in got:
-        assert gb.shape == (6, 5, 6) and np.array_equal(gb[:3], local[0]) and np.array_equal(gb[3:], local[1])   # rank order == image order
-        assert gc.tolist() == [1, 0, 5, 2, 0, 5]
-    lists = ydist.records_to_lists(torch.from_numpy(got[0][1]), torch.from_numpy(got[0][2]))
-    assert [len(l) for l in lists] == [1, 0, 5, 2, 0, 5]
-    assert isinstance(lists[0][0][4], int) and 0 <= lists[0][0][4] < 80
+    want = _expected(TAGS)
+    for rank, shape, counts, status, lists, pred, pred1, calls in got:
+        assert shape == (2, 3, 6, 6)                                    # [world, B, K, 6]: rank order == image order
+        assert counts == [[1, 3, 0], [5, 2, 0]] and status == [[0, 0, 0], [0, 0, 0]]     # the padded slot of rank 1 reads count 0
+        flat = [lists[0], lists[1], lists[2], lists[3], lists[4]]       # slots rank-major; slot 5 is the pad
+        for img, w in zip(flat, want):
+            assert [tuple(np.float32(v) for v in b) for b in img] == [tuple(np.float32(v) for v in b) for b in w]
+        assert lists[5] == []
+        assert len(pred) == 5
+        for img, w in zip(pred, want):                                  # Yolo.predict: same global list on every rank
+            assert [(np.float32(b[0]), b[1], b[4]) for b in img] == [(np.float32(v[0]), v[1], v[4]) for v in w]
+        assert len(pred1) == 1 and len(pred1[0]) == 1
+        assert calls == (3 if rank == 0 else 2)                         # rank 1 ran no kernels for the 1-image batch
 
 
 def test_single_process_is_identity():
-    b, c = torch.zeros(2, 4, 6), torch.zeros(2, dtype=torch.int32)
-    gb, gc, gs = ydist.gather_records(b, c)
-    assert gb is b and gc is c and gs is None
+    eng = StandInEngine(max_batch=2, max_boxes=4)
+    x = torch.stack([torch.full((2, 2, 3), 0.25), torch.full((2, 2, 3), 0.5)])
+    boxes, counts, status = ydist.detect_sharded(eng, x, 0.5, 0.6)
+    assert boxes.shape == (1, 2, 4, 6) and counts.tolist() == [[2, 4]]
+    assert boxes.data_ptr() == eng._boxes.data_ptr()                    # no gather, no copy
+
+
+def test_bench_self_launches_ranks_without_a_gpu():
+    """`python bench.py --gpus 2` as the driver calls it (no WORLD_SIZE): it must start two ranks itself, and in this
+    GPU-less container both must end with the 'no GPU' error -- not with a usage error before any rank exists."""
+    import pytest
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU (on the GPU box this would launch a real 2-GPU benchmark)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode not in (0, 2), r.stderr[-2000:]
+    assert "rank 0 needs GPU 0" in r.stderr and "rank 1 needs GPU 1" in r.stderr, r.stderr[-2000:]

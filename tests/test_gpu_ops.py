@@ -25,10 +25,10 @@ def oracle_out(net, w, x, dtype, keep=None):
     return FR.forward(L, w, x, keep=keep, storage="fp16" if dtype == "fp16" else None)
 
 
-def check_graph(net, x, dtype, seed=0, read=(), max_batch=None):
+def check_graph(net, x, dtype, seed=0, read=(), max_batch=None, tile=None):
     w = synth.darknet_stream(net, seed=seed)
     want, kept = oracle_out(net, w, x, dtype, keep=set(read))
-    got, eng = run_hip(net, w, x, dtype, keep_all=bool(read), max_batch=max_batch)
+    got, eng = run_hip(net, w, x, dtype, keep_all=bool(read), max_batch=max_batch, force_tile=tile)
     assert got.shape == want.shape, (got.shape, want.shape)
     errs = {"final": rel_err(got, want)}
     for i in read:
@@ -243,11 +243,10 @@ def test_fused_stem(shape):
 
 
 @pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13])
-def test_tap_reuse_tile_configs(tile, monkeypatch):
+def test_tap_reuse_tile_configs(tile):
     """tap-reuse tiles of conv_tap.hip (3x3/1 only: patch of 1, 2, 4 and 6 channel slices, image borders inside a
-    block, position tail; the other layers fall back to the default choice) forced through YOLO_CONV_TILE: K-stage counts 1, 2 (shorter than the
+    block, position tail; the other layers fall back to the default choice) forced through yolo_net_options.force_tile: K-stage counts 1, 2 (shorter than the
     LDS ring), 4, 9 (odd), 18, 36, 54 and 72, residual, stride 2, M tails, Cout 255 head"""
-    monkeypatch.setenv("YOLO_CONV_TILE", str(tile))
     g = new_graph(21, 19, 3)
     g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))                  # 1  first-layer kernel
     g.append(PL.conv2d_bn_act(g[-1].out, 128, 1, 1))                 # 2  Cin 32 1x1: 1 stage
@@ -266,7 +265,7 @@ def test_tap_reuse_tile_configs(tile, monkeypatch):
     g.append(PL.conv2d_bn_act(g[-1].out, 512, 3, 1))                 # 15 72 stages, two cout tiles
     g.append(PL.conv2d_bn_act(g[-1].out, 255, 1, 1, use_batch_normalization=False, activation_fn="linear"))   # 16 head
     x = synth.synthetic_input(5, 21, 19, 3, seed=12)
-    eng = check_graph(g, x, "fp16", seed=4, read=(2, 4, 6, 9, 11, 14, 15))
+    eng = check_graph(g, x, "fp16", seed=4, read=(2, 4, 6, 9, 11, 14, 15), tile=tile)
     names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
     assert "tap9" in names, names
 
@@ -274,11 +273,10 @@ def test_tap_reuse_tile_configs(tile, monkeypatch):
 @pytest.mark.parametrize("shape", [(2, 19, 19, 512, 256), (3, 38, 38, 64, 128), (1, 76, 76, 128, 256), (2, 7, 78, 32, 128),
                                    (2, 5, 110, 64, 128), (1, 9, 152, 64, 128), (2, 33, 100, 32, 64), (1, 48, 304, 32, 64)])
 @pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13])
-def test_tap_reuse_conv_shapes(shape, tile, monkeypatch):
+def test_tap_reuse_conv_shapes(shape, tile):
     """conv_tap.hip on the feature-map sizes of YOLOv3-608 (19, 38, 76), the widest rows its padded-linear tiles take
     (78, 110, 158 >= 152), wide maps for the 2-D tiles (partial 16x16 tiles in both directions, Cout 64) and a residual
     input: blocks span image rows, images and the end of the batch"""
-    monkeypatch.setenv("YOLO_CONV_TILE", str(tile))
     B, H, W, cin, cout = shape
     g = new_graph(H, W, cin)
     g.append(PL.conv2d_bn_act(g[-1].out, cout, 3, 1))
@@ -287,9 +285,9 @@ def test_tap_reuse_conv_shapes(shape, tile, monkeypatch):
     g.append(PL.shortcut(g[-1].out, g[-3].out))
     g.append(PL.max_pool2d(g[-1].out, 2, stride=1))
     x = synth.synthetic_input(B, H, W, cin, seed=21)
-    eng = check_graph(g, x, "fp16", seed=5, read=(1, 4))
+    eng = check_graph(g, x, "fp16", seed=5, read=(1, 4), tile=tile)
     if tile in (8, 12, 13) and W <= 110:         # the float32 instantiation (16-channel slices, exact fp32 FMA chain): 1e-4 contract
-        eng32 = check_graph(g, x, "fp32", seed=5, read=(1, 4))
+        eng32 = check_graph(g, x, "fp32", seed=5, read=(1, 4), tile=tile)
         if dict(((8, cout > 64 and W <= 78), (12, cout > 64), (13, cout == 64)))[tile]:
             assert "tap9" in " ".join(ki.name.decode() for ki in eng32.kernel_infos())
     names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
@@ -300,11 +298,10 @@ def test_tap_reuse_conv_shapes(shape, tile, monkeypatch):
 
 
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 14])
-def test_every_dma_tile_config(tile, monkeypatch):
-    """each LDS-DMA tile shape of conv_dma.hip, forced through YOLO_CONV_TILE (read at every launch; a tile
+def test_every_dma_tile_config(tile):
+    """each LDS-DMA tile shape of conv_dma.hip, forced through yolo_net_options.force_tile (a tile
     that is not valid for a layer falls back to the heuristic), on a graph with 3x3/1, 3x3/2, 1x1, residual,
     Cin=32 (one tap per K=32 stage), Cout=64 (weight tile smaller than the wave count) and M tails"""
-    monkeypatch.setenv("YOLO_CONV_TILE", str(tile))
     g = new_graph(20, 24, 3)
     g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))                  # 1  first-layer kernel
     g.append(PL.conv2d_bn_act(g[-1].out, 64, 3, 2))                  # 2  Cin 32, Cout 64 (tile 7)
@@ -318,6 +315,6 @@ def test_every_dma_tile_config(tile, monkeypatch):
     g.append(PL.shortcut(g[-1].out, g[-3].out))                      # 10
     g.append(PL.conv2d_bn_act(g[-1].out, 255, 1, 1, use_batch_normalization=False, activation_fn="linear"))   # 11 head
     x = synth.synthetic_input(3, 20, 24, 3, seed=11)
-    eng = check_graph(g, x, "fp16", seed=3, read=(2, 5, 7, 10))
+    eng = check_graph(g, x, "fp16", seed=3, read=(2, 5, 7, 10), tile=tile)
     names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
     assert "conv_igemm_dma" in names

@@ -137,3 +137,112 @@ def test_small_v3_forward_runs_and_fp16_emulation_is_close():
     assert y.shape == (1, (4 + 16 + 64) * 3, 85)
     y16 = FR.forward(L, Wd, x, storage="fp16")
     assert np.max(np.abs(y - y16)) < 5e-2 * max(1.0, np.max(np.abs(y)))
+
+
+# ---- topology + weight order pinned to the reference's OWN builders --------------------------------------------
+# tests/golden/topology_*.json are what net/v2.py:11-60 / net/v3.py:9-94 built when run under a recording `tensorflow`
+# module in the build container (oracle/gen_topology.py): per layer the class, the recorded TF ops with their
+# arguments, the source layers by `.out` identity, the shape and `.variable_names`.
+
+def _fixture_to_tuples(fx):
+    """golden records -> oracle/topology tuples, checking the op arguments the restatement relies on."""
+    out = []
+    for l in fx["layers"]:
+        ops = {o["op"]: o for o in l["ops"]}
+        names = [o["op"] for o in l["ops"] if o["op"] != "identity"]     # tf.identity only renames the last layer (v2.py:59, v3.py:93)
+        c = l["class"]
+        if c == "input_layer":
+            assert names == ["placeholder"] and ops["placeholder"]["dtype"] == "float32" and l["shape"][0] is None
+            out.append(("input",) + tuple(l["shape"][1:]))
+        elif c == "conv2d_bn_act":
+            cv = ops["conv2d"]
+            k, s = cv["kernel_size"][0], cv["strides"][0]
+            bn, leaky = "batch_normalization" in ops, "leaky_relu" in ops
+            assert names == (["pad"] if s > 1 else []) + ["conv2d"] + (["batch_normalization"] if bn else []) + (["leaky_relu"] if leaky else [])
+            assert cv["kernel_size"] == [k, k] and cv["strides"] == [s, s] and cv["padding"] == ("SAME" if s == 1 else "VALID")     # layers.py:28-30
+            assert cv["use_bias"] == (not bn)                                                                                    # layers.py:37
+            if s > 1:       # layers.py:9-14: (k-1)//2 before, the rest after, H and W only, zeros
+                a = (k - 1) // 2
+                assert ops["pad"]["paddings"] == [[0, 0], [a, k - 1 - a], [a, k - 1 - a], [0, 0]] and ops["pad"]["mode"] == "CONSTANT"
+            if bn:
+                assert ops["batch_normalization"]["epsilon"] == 1e-5 and ops["batch_normalization"]["training"] is False      # layers.py:5
+            if leaky:
+                assert ops["leaky_relu"]["alpha"] == 0.1                                                                          # layers.py:6
+            out.append(("conv", l["src"][0], cv["filters"], k, s, bn, "leaky" if leaky else "linear"))
+        elif c == "max_pool2d":
+            mp = ops["max_pooling2d"]
+            k, s = mp["pool_size"][0], mp["strides"][0]
+            assert names == (["pad"] if s > 1 else []) + ["max_pooling2d"] and mp["padding"] == ("SAME" if s == 1 else "VALID")
+            if s > 1:
+                assert ops["pad"]["paddings"] == [[0, 0], [0, 1], [0, 1], [0, 0]]           # (k-1)//2 = 0 before, 1 after
+            out.append(("maxpool", l["src"][0], k, s))
+        elif c == "route":
+            assert names == ["concat"] and ops["concat"]["axis"] == 3
+            out.append(("route", list(l["src"])))
+        elif c == "reorg":
+            e = ops["extract_image_patches"]
+            assert names == ["extract_image_patches"] and e["ksizes"] == e["strides"] and e["rates"] == [1, 1, 1, 1] and e["padding"] == "VALID"
+            out.append(("reorg", l["src"][0], e["ksizes"][1]))
+        elif c == "shortcut":
+            assert names == ["add"]
+            out.append(("shortcut", l["src"][0], l["src"][1]))
+        elif c == "upsample":
+            assert names == ["resize_nearest_neighbor"]
+            out.append(("upsample", l["src"][0], l["shape"][1] // fx["layers"][l["src"][0]]["shape"][1]))
+        elif c == "yolo_layer":
+            assert names == ["reshape"] and ops["reshape"]["new_shape"] == [-1, l["h"] * l["w"] * l["b"], 5 + fx["num_classes"]]
+            out.append(("yolo", l["src"][0], [tuple(a) for a in l["anchors"]]))
+        elif c == "detection_layer":
+            assert names == ["concat"] and ops["concat"]["axis"] == 1
+            out.append(("detection", list(l["yolos"])))
+        else:
+            raise AssertionError(c)
+    return out
+
+
+@pytest.mark.parametrize("name", ["v2_416", "v3_416", "v3_608"])
+def test_topology_and_weight_order_equal_the_reference_builders(name):
+    import json
+    import os
+    from helpers import GOLDEN
+    fx = json.load(open(os.path.join(GOLDEN, "topology_%s.json" % name)))
+    size = tuple(fx["input_shape"])
+    anchors = np.reshape(fx["anchors"], [-1, 2])
+    if fx["net"] == "v2":
+        net = v2.create_full_network(anchors, NAMES80, False, input_shape=size)
+        oracle = T.yolov2(len(anchors), 80, size)
+    else:
+        net = v3.create_network(anchors, NAMES80, False, input_shape=size)
+        oracle = T.yolov3(fx["anchors"], 80, size)
+    ref = _fixture_to_tuples(fx)
+    got = to_oracle(net)
+    assert len(ref) == len(got) == len(oracle)
+    S = T.shapes(oracle)
+    for i, (r, g, o) in enumerate(zip(ref, got, oracle)):
+        if r[0] == "yolo":          # reference and product: grid units, float64 (layers.py:131); oracle topology: pixels
+            stride = size[0] / S[o[1]][0]
+            assert r[:2] == g[:2] == o[:2]
+            assert np.array_equal(np.array(r[2]), np.array(g[2])) and np.allclose(np.array(r[2]) * stride, np.array(o[2]))
+        else:
+            assert r == g == o, (i, r, g, o)
+        shp = fx["layers"][i]["shape"][1:]      # output shapes as TensorFlow's shape inference gives them
+        if r[0] == "yolo":          # [-1, h*w*b, 5+C] view of the head conv (layers.py:133)
+            h, w, ch = S[i]
+            assert shp == [h * w * len(r[2]), 85] and ch == len(r[2]) * 85 and net[i].rows == shp[0]
+        elif r[0] == "detection":
+            assert shp == [sum(net[j].rows for j in r[1]), 85] == [net[i].out.hwc[0], net[i].out.hwc[2]]
+        else:
+            assert tuple(shp) == tuple(S[i]) == tuple(net[i].out.hwc), i
+    # Darknet stream order (net/base.py:26-46 walks layers x variable_names): same names in the same order
+    assert [l["variable_names"] for l in fx["layers"]] == [list(l.variable_names) for l in net]
+    # ... and the oracle's weight parser consumes per conv exactly those tensors in that order
+    flat = np.arange(T.conv_weight_count(oracle), dtype=np.float32)
+    parsed = FR.parse_darknet_weights(oracle, flat)
+    pos = 0
+    for i, l in enumerate(fx["layers"]):
+        for vn in l["variable_names"]:
+            key = vn.rsplit("/", 1)[1]
+            arr = parsed[i][{"beta": "beta", "gamma": "gamma", "moving_mean": "mean", "moving_variance": "var", "bias": "bias", "kernel": "kernel_oihw"}[key]]
+            assert arr.ravel()[0] == pos, (i, vn)
+            pos += arr.size
+    assert pos == flat.size
