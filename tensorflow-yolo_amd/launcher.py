@@ -16,7 +16,7 @@ import os
 import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_CONFIG = os.path.join(_PKG, "config", "yolov2_coco.ini")
+DEFAULT_CONFIG = os.path.join(_PKG, "config", "yolo_2.ini")
 LITERAL_KEYS = ("anchors", "class_names")
 PATH_SUFFIXES = ("_dir", "_path")
 

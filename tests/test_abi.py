@@ -124,3 +124,40 @@ def test_detection_head_geometry_roundtrip():
     _hip.check(p.lib.yolo_net_head_desc(p.handle, C.byref(hd)))
     assert hd.n_classes == 80 and [hd.n_anchors[i] for i in range(3)] == [3, 3, 3]
     assert abs(hd.anchors[0][0] - 116 / 32) < 1e-12 and abs(hd.anchors[2][1] - 13 / 8) < 1e-12
+
+
+def test_kernel_info_symbols_are_real_kernels_of_the_library():
+    """yolo_kernel_info.symbol (what bench.py prints as roofline.kernel_symbol) must be the name rocprofv3's kernel trace
+    prints: the demangled kernel name.  Every symbol the plans of the three networks report, in both dtypes, has to be a
+    kernel handle exported by libyolo_hip.so (`nm -DC`), and a kernel without a launch of its own reports \"\"."""
+    import ctypes as C
+    import subprocess
+    import numpy as np
+    from oracle import cases
+    from tensorflow_yolo_amd import _hip
+    from tensorflow_yolo_amd.net import engine, v2, v3
+    exported = set()
+    for line in subprocess.check_output(["nm", "-DC", _hip.LIB_PATH], text=True).splitlines():
+        parts = line.split(" ", 2)
+        if len(parts) == 3 and "yolo::" in parts[2]:
+            exported.add(parts[2].strip())
+    assert any("conv3x3_tap_kernel" in e for e in exported)
+    names = ["c%d" % i for i in range(80)]
+    nets = [v2.create_full_network(np.reshape(cases.COCO_V2_ANCHORS, [-1, 2]), names, False),
+            v2.create_tiny_network(np.reshape(cases.VOC_TINY_ANCHORS, [-1, 2]), names[:20], False),
+            v3.create_network(np.reshape(cases.COCO_V3_ANCHORS, [-1, 2]), names, False, input_shape=(608, 608, 3))]
+    seen = set()
+    for net in nets:
+        for dtype in ("fp16", "fp32"):
+            for batch in (1, 32):
+                p = engine.Plan(net, dtype=dtype, max_batch=batch)
+                for k in range(p.num_kernels):
+                    ki = _hip.KernelInfo()
+                    _hip.check(p.lib.yolo_net_kernel_info(p.handle, k, C.byref(ki)), "yolo_net_kernel_info")
+                    sym = ki.symbol.decode()
+                    if "fused into" in ki.name.decode():
+                        assert sym == ""
+                        continue
+                    assert sym in exported, (ki.name.decode(), sym)
+                    seen.add(sym)
+    assert len(seen) >= 10

@@ -32,7 +32,7 @@ def test_logits_fp32_within_1e4(kind, size, batch):
     assert got.shape == want.shape
     err = float(np.max(np.abs(got.astype(np.float64) - want)))
     print("%s-%d b%d fp32: max|logit| %.3f  max abs err %.3e  kernels %d" % (kind, size, batch, np.abs(want).max(), err, eng.num_kernels))
-    assert err <= 1e-4 * max(1.0, float(np.abs(want).max())), err
+    assert err <= 1e-4, err            # ABSOLUTE, as north_star states it ("within 1e-4 on logits")
 
 
 @pytest.mark.parametrize("kind,size,batch", [("v2", 416, 2), ("tiny", 416, 2), ("v3", 160, 2), ("v3", 320, 1)])
@@ -129,8 +129,128 @@ def test_multi_stream_forward_and_detect(streams):
     assert rel_err(b, a) <= 5e-3
     per = (6 + streams - 1) // streams
     assert rel_err(many.forward(x[:per]).cpu().numpy(), a[:per]) <= 5e-3          # fits arena 0: single pass
-    ra, rb = one.detect(x, 0.3, 0.5), many.detect(x, 0.3, 0.5)
-    ca, cb = ra[1].cpu().numpy(), rb[1].cpu().numpy()
-    assert (np.abs(ca.astype(int) - cb.astype(int)) <= 1).all() and not rb[2].cpu().numpy().any()
+    # boxes: every part runs the kernels the single pass runs unless its batch picks another tile (K order), so the two
+    # modes may differ by fp16 summation-order noise e -- the margin rule (oracle/parity.py) decides: identical box sets
+    # unless a score sits within the flip band of the threshold or an IoU within it of the IoU threshold
+    from oracle import decode_ref, parity
+    from tensorflow_yolo_amd.net import engine as E
+    e = float(np.max(np.abs(a.astype(np.float64) - b)))
+    recs_a, _ = E.records_to_host(*one.detect(x, 0.3, 0.5))
+    recs_b, st = E.records_to_host(*many.detect(x, 0.3, 0.5))
+    assert not st.any()
+    sc = decode_ref.v3_scales(cases.COCO_V3_ANCHORS, (160, 160))
+    rep = parity.check(a, b, recs_b, 3, 0.3, 0.5, scales=sc)           # reference here = the single-pass logits
+    want = decode_ref.find_bounding_boxes_v3(a, 0.3, 0.5, sc)
+    for i in range(6):                                                  # the single pass itself is exact against its own logits
+        from helpers import match_boxes
+        match_boxes(recs_a[i], [bb.astuple() for bb in want[i]])
+    print("streams=%d: max|dlogit| %.2e, margins p %.2e iou %s, identity required %s, match %s"
+          % (streams, e, rep["prob_margin"], rep["iou_margin"], rep["identity_required"], rep["box_set_match"]))
+    parity.assert_ok(rep, min_matched_frac=0.98)
     ms = many.forward_timed(x)
     assert len(ms) == many.num_kernels and float(np.sum(ms)) > 0
+
+
+# ---- the BASELINE.json configurations at their stated batch sizes (VERDICT r1: tile choice depends on M = B*Ho*Wo, so batch 2
+# exercises other tiles than batch 16 / 64) ----------------------------------------------------------------------------------
+def _oracle_threads():
+    import torch
+    t = torch.get_num_threads()
+    torch.set_num_threads(min(32, t))           # MKL-DNN convs on the GPU box's host are fastest at ~32 threads
+    return t
+
+
+def test_config2_v2_416_batch16_fp16_full_size():
+    """BASELINE.json configs[1]: YOLOv2 416x416 batch 16 fp16 -- all 16 images against the fp16-storage emulation of the
+    oracle, distance to the fp32 oracle reported, and the post-NMS boxes against the FP32 oracle pipeline under the
+    margin rule (SURVEY 7.3 #3, oracle/parity.py)"""
+    import torch
+    from oracle import parity
+    from tensorflow_yolo_amd import YoloV2
+    net, nc = build("v2", 416)
+    hg, frac = synth.HEAD_DEFAULTS["v2"]
+    w = synth.darknet_stream(net, seed=5, num_classes=nc, head_gain=hg, obj_bias=0.0)
+    x = synth.synthetic_input(16, 416, 416, 3, seed=6)
+    model = YoloV2()
+    model.build(cases.COCO_V2_ANCHORS, NAMES80, (416, 416, 3), dtype="fp16", max_batch=16, weights=w)
+    w = synth.calibrate_model(model, x[:2], frac)
+    L = to_oracle(net)
+    t = _oracle_threads()
+    try:
+        want16 = FR.forward(L, w, x, storage="fp16")
+        want32 = FR.forward(L, w, x)
+    finally:
+        torch.set_num_threads(t)
+    got = model.forward(x)
+    e16 = rel_err(got, want16)
+    boxes = model.predict(x, 0.5, 0.6)
+    rep = parity.check(want32, got, [[(b.x, b.y, b.w, b.h, b.class_idx, b.prob) for b in img] for img in boxes], 2, 0.5, 0.6,
+                       anchors=cases.COCO_V2_ANCHORS, num_classes=80)
+    print("v2-416 b16 fp16: rel vs fp16-emulating oracle %.2e; vs fp32 oracle: %s" % (e16, rep))
+    names = " ".join(ki.name.decode() for ki in model.net.engine.kernel_infos())
+    print(names)
+    assert e16 <= 2e-2, e16
+    parity.assert_ok(rep)
+
+
+def test_config5_tiny_v2_voc_batch64_fp32_full_size():
+    """BASELINE.json configs[4]: tiny-YOLOv2-VOC 416x416 batch 64 fp32 -- every image within 1e-4 ABSOLUTE of the fp32
+    oracle and identical post-NMS boxes"""
+    import torch
+    from oracle import parity
+    from tensorflow_yolo_amd import YoloV2Tiny
+    net, nc = build("tiny", 416)
+    hg, frac = synth.HEAD_DEFAULTS["v2-tiny"]
+    w = synth.darknet_stream(net, seed=5, num_classes=nc, head_gain=hg, obj_bias=0.0)
+    x = synth.synthetic_input(64, 416, 416, 3, seed=6)
+    model = YoloV2Tiny()
+    model.build(cases.VOC_TINY_ANCHORS, NAMES20, (416, 416, 3), dtype="fp32", max_batch=64, weights=w)
+    w = synth.calibrate_model(model, x[:2], frac)
+    t = _oracle_threads()
+    try:
+        want = FR.forward(to_oracle(net), w, x)
+    finally:
+        torch.set_num_threads(t)
+    got = model.forward(x)
+    boxes = model.predict(x, 0.5, 0.6)
+    rep = parity.check(want, got, [[(b.x, b.y, b.w, b.h, b.class_idx, b.prob) for b in img] for img in boxes], 2, 0.5, 0.6,
+                       anchors=cases.VOC_TINY_ANCHORS, num_classes=20)
+    print("tiny-v2-voc b64 fp32:", rep)
+    assert rep["max_abs_logit_err"] <= 1e-4, rep
+    parity.assert_ok(rep)
+    assert rep["box_set_match"] or not rep["identity_required"], rep
+
+
+def test_v3_608_fp32_within_1e4_and_fp16_boxes_vs_fp32_oracle():
+    """YOLOv3 608x608, two images: (a) the fp32 net against the fp32 oracle -- 1e-4 ABSOLUTE on the logits, identical boxes;
+    (b) BASELINE.json configs[2]'s fp16 net: its post-NMS boxes against the FP32 oracle pipeline (not against a decode of
+    its own logits) under the margin rule, with the margins printed"""
+    import torch
+    from oracle import decode_ref, parity
+    from tensorflow_yolo_amd import YoloV3
+    net, nc = build("v3", 608)
+    hg, frac = synth.HEAD_DEFAULTS["v3"]
+    w = synth.darknet_stream(net, seed=5, num_classes=nc, head_gain=hg, obj_bias=0.0)
+    x = synth.synthetic_input(2, 608, 608, 3, seed=9)
+    m32 = YoloV3()
+    m32.build(cases.COCO_V3_ANCHORS, NAMES80, (608, 608, 3), dtype="fp32", max_batch=2, weights=w)
+    w = synth.calibrate_model(m32, x, frac)
+    t = _oracle_threads()
+    try:
+        want = FR.forward(to_oracle(net), w, x)
+    finally:
+        torch.set_num_threads(t)
+    sc = decode_ref.v3_scales(cases.COCO_V3_ANCHORS, (608, 608))
+    got32 = m32.forward(x)
+    b32 = m32.predict(x, 0.5, 0.6)
+    rep32 = parity.check(want, got32, [[(b.x, b.y, b.w, b.h, b.class_idx, b.prob) for b in img] for img in b32], 3, 0.5, 0.6, scales=sc)
+    print("v3-608 b2 fp32: max|logit| %.2f  %s" % (float(np.abs(want).max()), rep32))
+    assert rep32["max_abs_logit_err"] <= 1e-4, rep32
+    parity.assert_ok(rep32)
+    m16 = YoloV3()
+    m16.build(cases.COCO_V3_ANCHORS, NAMES80, (608, 608, 3), dtype="fp16", max_batch=2, weights=w)
+    got16 = m16.forward(x)
+    b16 = m16.predict(x, 0.5, 0.6)
+    rep16 = parity.check(want, got16, [[(b.x, b.y, b.w, b.h, b.class_idx, b.prob) for b in img] for img in b16], 3, 0.5, 0.6, scales=sc)
+    print("v3-608 b2 fp16 vs the fp32 oracle pipeline:", rep16)
+    parity.assert_ok(rep16)

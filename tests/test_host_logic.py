@@ -14,7 +14,7 @@ CFG_DIR = os.path.join(ROOT, "tensorflow-yolo_amd", "config")
 
 
 def test_ini_surface_and_path_resolution():
-    cfg = launcher.read_config(os.path.join(CFG_DIR, "yolov3_coco.ini"))
+    cfg = launcher.read_config(os.path.join(CFG_DIR, "yolo_3.ini"))
     assert set(cfg) >= {"COMMON", "TEST"}
     t = cfg["TEST"]
     for key in ("image_dir", "out_dir", "batch_size", "threshold", "iou_threshold", "anchors", "class_names",
@@ -27,7 +27,7 @@ def test_ini_surface_and_path_resolution():
     merged = dict(t)
     merged.update(cfg["COMMON"])
     assert merged["version"] == "v3" and merged["threshold"] == "0.5"
-    for name, ver, n in (("yolov2_coco.ini", "v2", 10), ("yolov2_tiny_voc.ini", "v2-tiny", 10)):
+    for name, ver, n in (("yolo_2.ini", "v2", 10), ("yolov2_tiny_voc.ini", "v2-tiny", 10)):
         c = launcher.read_config(os.path.join(CFG_DIR, name))
         assert c["COMMON"]["version"] == ver and len(c["TEST"]["anchors"]) == n
 
@@ -42,7 +42,7 @@ def test_launcher_flags_defaults_and_unsupported_modes(tmp_path):
     with pytest.raises(ValueError, match="Unsupported version"):
         launcher.main(["--config", str(bad), "--mode", "test"])
     with pytest.raises(ValueError, match="Unsupported mode"):
-        launcher.main(["--config", os.path.join(CFG_DIR, "yolov3_coco.ini"), "--mode", "bogus"])
+        launcher.main(["--config", os.path.join(CFG_DIR, "yolo_3.ini"), "--mode", "bogus"])
     assert isinstance(launcher.pick_model("v2"), YoloV2) and isinstance(launcher.pick_model("v3"), YoloV3)
 
 
