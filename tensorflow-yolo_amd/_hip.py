@@ -102,6 +102,10 @@ def lib():
             "libyolo_hip.so not found at %s: the HIP extension is the only compute path of this package "
             "(no CPU fallback). Build it with `python __graft_entry__.py` or `make -C tensorflow-yolo_amd/csrc`."
             % LIB_PATH)
+    # torch first: libyolo_hip.so links the system libamdhip64 while torch-ROCm carries its own copy; whichever is loaded first
+    # serves both, and a process that loaded the system copy before torch ends up with two HIP runtimes of which ours sees no
+    # device ("no ROCm-capable device is detected" from hipMemcpy).  torch is this package's device-memory plumbing anyway.
+    import torch  # noqa: F401
     handle = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(handle, name)      # AttributeError if the symbol is not exported

@@ -30,7 +30,7 @@ namespace yolo {
 // WM x WN waves; a wave owns TM*16 couts x TP*16 pixels.
 // (F32 rather than the element type as template parameter: see conv_tap.hip)
 template <bool F32, int WM, int WN, int TM, int TP, bool PERCHUNK>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
+__global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams p) {      // two workgroups per CU: <= 256 registers
     typedef typename std::conditional<F32, float, _Float16>::type T;
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int NA = WM * TM * 16;        // couts per block
@@ -129,10 +129,14 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     };
 
     float4v acc[TM][TP];
+    float4v acc2[F32 ? TM : 1][F32 ? TP : 1];       // float32: second-level accumulator (conv_common.h: flush_acc)
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TP; ++b) acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < TP; ++b) {
+            acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
+            if (F32) acc2[F32 ? a : 0][F32 ? b : 0] = float4v{0.f, 0.f, 0.f, 0.f};
+        }
 
     const int fr = lane & 15, fq = lane >> 4;
     auto compute = [&](int buf) {
@@ -162,8 +166,17 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
         const bool more = kt + 1 < p.ktiles;
         if (more) load_tile(kt + 1);
         compute(cur);
+        if constexpr (F32) {            // a K tile is 32 floats deep: restart the chain every 256 k
+            if ((kt & 7) == 7 || !more) flush_acc<TM, TP>(acc, acc2);
+        }
         if (more) store_tile(cur ^ 1);
         __syncthreads();
+    }
+    if constexpr (F32) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TP; ++b) acc[a][b] = acc2[a][b];
     }
 
     // ---- epilogue: bias, leaky, residual, store (conv_common.h) -------------------------------

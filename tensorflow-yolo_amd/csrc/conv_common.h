@@ -33,6 +33,22 @@ __device__ __forceinline__ float4v mma_chunk<float>(const uint4v &a, const uint4
     return c;
 }
 
+// float32 nets: TWO-LEVEL accumulation.  An f32 MFMA accumulates as one k-ordered fmaf chain, so a 3x3 conv over 1024 input
+// channels is a sequential sum of 9216 products: rounding error ~ sqrt(K) ulp of the running sum (measured: 1.3e-4 on
+// logits of +-30 through Darknet-19, four times the error of a blocked CPU summation, and above the 1e-4 the fp32 path
+// is held to).  The K loop therefore adds its accumulator into a second one every <= 288 k and restarts from zero:
+// chain lengths 288 and K / 288 instead of K.
+template <int TM, int TP>
+__device__ __forceinline__ void flush_acc(float4v (&acc)[TM][TP], float4v (&acc2)[TM][TP]) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) {
+            acc2[a][b] += acc[a][b];
+            acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
+        }
+}
+
 // Epilogue of one wave: acc[a][b] is the 16x16 tile (cout tile a, pixel tile b); with the
 // cout <-> LDS-row permutation of the staging code a lane owns CH = 4*TM CONTIGUOUS couts
 // (cbase ..) of pixel (m_wave + 16 b + fr).  bias (folded BN) -> leaky 0.1 (layers.py:6,51) ->

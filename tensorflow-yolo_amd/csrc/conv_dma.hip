@@ -246,6 +246,7 @@ static const int kNumCfgs = 15;
 static const int kFirstTapCfg = 8, kLastTapCfg = 13;
 static inline bool is_tap_cfg(int cfg) { return cfg >= kFirstTapCfg && cfg <= kLastTapCfg; }
 bool dma_cfg_is_tap(int cfg) { return is_tap_cfg(cfg); }
+bool dma_cfg_f32_ok(int cfg) { return is_tap_cfg(cfg) && conv_tap_f32_ok(cfg - kFirstTapCfg); }
 
 // Pick the block tile that minimises rounds x tile time on 256 CUs (tail quantisation matters:
 // e.g. 38x38x512 at batch 32 is 362 tiles of 256x256 = 2 rounds at 71 % but 722 of 256x128 = 3 at 94 %).
@@ -305,7 +306,7 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
     for (int c = 0; c < kNumCfgs; ++c) {
         // float32 nets: only conv_tap.hip has a float32 instantiation, and it beats the 4-wave kernel by ~10 % on every 3x3/1
         // layer measured (tiny-YOLOv2 b64: 1024->1024 at 13x13 2.26 -> 2.06 ms), so the 4-wave kernel is only the fallback
-        if (tap_only && !is_tap_cfg(c)) continue;
+        if (tap_only && !dma_cfg_f32_ok(c)) continue;
         if (c == 12 && W <= 110) continue;      // the padded-linear tiles fit and measured faster (104x104: 70 vs 84 us)
         if (c == 14 && taps != 1) continue;     // measured 10-20 % slower than the larger tiles on every 3x3 layer
         if (c == 7 || c == 13 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;

@@ -80,6 +80,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     static_assert(WM * WN == NW, "eight waves");
     static_assert(JA_TOT % NW == 0 || JA_TOT < NW, "weight tile must split evenly over the waves (or be smaller than them)");
     static_assert(MODE == 1 || PRG * 16 >= (NB / 16 + 2) * PW, "patch buffer too small for the 2-D tile");
+    if constexpr (F32 && TP > 2) return;    // never launched (launch_conv_tap refuses): no registers for the second accumulator
     __shared__ __attribute__((aligned(16))) unsigned char smem[S * A_BYTES + 2 * P_BYTES];
     unsigned char *const smemP = smem + S * A_BYTES;
 
@@ -168,10 +169,16 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     };
 
     float4v acc[TM][TP];
+    // float32: second-level accumulator (conv_common.h: flush_acc); only the TP <= 2 tiles have the registers for it at
+    // two workgroups per CU, so those are the float32 tiles (kTapF32)
+    float4v acc2[F32 ? TM : 1][F32 ? TP : 1];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TP; ++b) acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < TP; ++b) {
+            acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
+            if (F32) acc2[F32 ? a : 0][F32 ? b : 0] = float4v{0.f, 0.f, 0.f, 0.f};
+        }
 
     const int fr = lane & 15, fq = lane >> 4;
     const int a_frag = (wm * TM * 16 + fr) * ROWB + (((fq ^ tap_swz_w(fr)) & 3) << 4);
@@ -239,6 +246,13 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     for (int c = 0; c < C; c += 2) {
         run_slice(c, std::integral_constant<int, 0>());
         if (c + 1 < C) run_slice(c + 1, std::integral_constant<int, 1>());
+        if constexpr (F32) flush_acc<TM, TP>(acc, acc2);        // two 16-channel slices x 9 taps = 288 k per chain
+    }
+    if constexpr (F32) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TP; ++b) acc[a][b] = acc2[a][b];
     }
     (void)KT;
 #ifdef YOLO_EXPERIMENT
@@ -263,7 +277,9 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
 // 4 = 128 x (16 x 16) and 5 = 64 x (16 x 16) 2-D tiles for maps wider than 78 (any width)
 static const int kTapNB[] = {256, 256, 192, 128, 256, 256};
 static const int kTapPRG[] = {26, 26, 26, 28, 27, 27};
+static const bool kTapF32[] = {false, false, false, true, false, true};      // float32 tiles: TP <= 2 (second-level accumulator)
 bool conv_tap_is2d(int variant) { return variant >= 4; }
+bool conv_tap_f32_ok(int variant) { return variant >= 0 && variant <= 5 && kTapF32[variant]; }
 bool conv_tap_fits(int variant, int W) {
     if (variant < 0 || variant > 5) return false;
     if (conv_tap_is2d(variant)) return true;
@@ -291,7 +307,8 @@ const char *conv_tap_symbol(int variant, bool f32) {
 }
 
 hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
-    if (p.ksize != 3 || p.stride != 1 || p.pad != 1 || p.Ho != p.H || p.Wo != p.W || (p.cin_chunks & 3) || !conv_tap_fits(variant, p.W))
+    if (p.ksize != 3 || p.stride != 1 || p.pad != 1 || p.Ho != p.H || p.Wo != p.W || (p.cin_chunks & 3) || !conv_tap_fits(variant, p.W) ||
+        (p.f32 && !conv_tap_f32_ok(variant)))
         return hipErrorInvalidValue;
     const dim3 grid((unsigned)p.n_blocks);
     switch (variant) {

@@ -217,6 +217,8 @@ hipError_t launch_conv_dma(const ConvParams &p, int cfg, hipStream_t s);
 hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s);       // conv_tap.hip: 3x3/1 with tap reuse
 bool conv_tap_fits(int variant, int W);
 bool conv_tap_is2d(int variant);
+bool conv_tap_f32_ok(int variant);            // float32 instantiation usable (tiles with room for the second accumulator)
+bool dma_cfg_f32_ok(int cfg);
 const char *dma_cfg_name(int cfg);
 // names exactly as rocprofv3's kernel trace prints them (yolo_kernel_info.symbol: joins bench.py's roofline to profiles/*.csv)
 const char *dma_cfg_symbol(int cfg, bool f32);

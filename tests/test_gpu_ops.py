@@ -286,9 +286,9 @@ def test_tap_reuse_conv_shapes(shape, tile):
     g.append(PL.max_pool2d(g[-1].out, 2, stride=1))
     x = synth.synthetic_input(B, H, W, cin, seed=21)
     eng = check_graph(g, x, "fp16", seed=5, read=(1, 4), tile=tile)
-    if tile in (8, 12, 13) and W <= 110:         # the float32 instantiation (16-channel slices, exact fp32 FMA chain): 1e-4 contract
+    if tile in (11, 13):        # the float32 tiles (16-channel slices, fp32 FMA chains restarted every 288 k: conv_common.h flush_acc): 1e-4 contract
         eng32 = check_graph(g, x, "fp32", seed=5, read=(1, 4), tile=tile)
-        if dict(((8, cout > 64 and W <= 78), (12, cout > 64), (13, cout == 64)))[tile]:
+        if dict(((11, cout > 64 and W <= 158), (13, cout == 64)))[tile]:
             assert "tap9" in " ".join(ki.name.decode() for ki in eng32.kernel_infos())
     names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
     max_w = {8: 78, 9: 78, 10: 110, 11: 158, 12: 1 << 20, 13: 1 << 20}[tile]
