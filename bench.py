@@ -295,7 +295,8 @@ def main():
             base, xb, ref_logits = cpu_baseline(kind, size, w, anchors, ncls, time_it=not args.no_cpu_baseline)
             out["cpu_baseline"] = base
             if not args.no_parity:
-                out["parity"] = parity_report(model, kind, size, anchors, ncls, xb, ref_logits, args.threshold, args.iou_threshold)
+                nb = min(batch, xb.shape[0])        # (a batch-1 workload checks one image)
+                out["parity"] = parity_report(model, kind, size, anchors, ncls, xb[:nb], ref_logits[:nb], args.threshold, args.iou_threshold)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
