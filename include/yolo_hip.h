@@ -92,8 +92,7 @@ typedef struct yolo_net_options {
     int32_t force_tile;     /* 0: per-layer tile choice (cost model / autotune); t + 1: run conv tile id t on every
                              * conv layer that accepts it (0 = 4-wave kernel, 1-7 and 14 LDS-DMA tiles, 8-13 tap-reuse
                              * tiles): test and tuning hook, any value gives the same results up to summation order   */
-    int32_t tap_tpw;        /* 0: built-in rule; n >= 1: every tap-reuse 3x3 conv runs n consecutive tiles per workgroup
-                             * (tuning hook like force_tile: same results)                                              */
+    int32_t reserved[1];
 } yolo_net_options;
 
 /* Result record; field names follow net/base.py:257-272 BoundingBox. */

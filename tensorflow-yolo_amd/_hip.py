@@ -31,7 +31,7 @@ class LayerDesc(C.Structure):
 
 class NetOptions(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("max_batch", C.c_int32), ("keep_all", C.c_int32),
-                ("cand_capacity", C.c_int32), ("max_boxes", C.c_int32), ("streams", C.c_int32), ("force_tile", C.c_int32), ("tap_tpw", C.c_int32)]
+                ("cand_capacity", C.c_int32), ("max_boxes", C.c_int32), ("streams", C.c_int32), ("force_tile", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class Box(C.Structure):

@@ -195,7 +195,6 @@ int make_conv_params(yolo_net *net, const Kernel &k, const Ptrs &P, int batch, C
     p.wrow_bytes = (uint32_t)k.ktiles * 128;
     p.leaky = k.leaky; p.outmode = k.outmode; p.has_res = k.has_res;
     p.f32 = dtype == YOLO_DTYPE_F32;
-    p.tpw = net->opt.tap_tpw > 0 ? net->opt.tap_tpw : 1;
     const int ch = k.cfg == CFG_N32 ? 8 : 16;
     const int oepc = p.out_f32 ? 4 : epc;
     p.vec_out = (k.cout % ch == 0) && (k.out.ld % oepc == 0) && ((k.out.base + k.out.coff) % oepc == 0) &&
@@ -537,9 +536,7 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         if (tile > 0) {
             out->variant = 8 + tile;
             snprintf(out->name, sizeof out->name, "conv_igemm_dma<%s,%s>", t, dma_cfg_name(tile));
-            const bool f32 = net->opt.dtype == YOLO_DTYPE_F32;
-            const int tpw = tap_tpw(tile, f32, (k.cout + dma_cfg_na(tile) - 1) / dma_cfg_na(tile), net->opt.tap_tpw > 0 ? net->opt.tap_tpw : 1);
-            set_symbol(dma_cfg_symbol(tile, f32, tpw > 1));
+            set_symbol(dma_cfg_symbol(tile, net->opt.dtype == YOLO_DTYPE_F32));
         } else {
             set_symbol(conv_symbol(net->opt.dtype, k.cfg, k.perchunk != 0));
             snprintf(out->name, sizeof out->name, "conv_igemm<%s,N%d,%s>", t, k.cfg == CFG_N128 ? 128 : k.cfg == CFG_N64 ? 64 : 32,

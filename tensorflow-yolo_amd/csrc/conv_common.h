@@ -95,9 +95,6 @@ template <typename T, int TM, int TP, int PADQ = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, float4v (&acc)[TM][TP], int cbase, int m_wave, int fr) {
     constexpr int CH = 4 * TM;
     constexpr int EPC = 16 / (int)sizeof(T);
-    constexpr int NCH = CH / EPC;           // 16-byte chunks of the lane's CH contiguous couts (fp16: TM / 2, fp32: TM)
-    constexpr int NI = TP * NCH;            // work items: (pixel fragment b, chunk h), i = b NCH + h
-    static_assert(CH % EPC == 0, "a lane owns whole 16-byte chunks");
     if (cbase >= p.Cout) return;
     const int nvalid = p.Cout - cbase < CH ? p.Cout - cbase : CH;
     {   // bias + activation in place: the bias registers die before the residual chunks arrive
@@ -114,31 +111,48 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, float4v (&acc
                     acc[a][b][j] = p.leaky ? fmaxf(0.1f * x, x) : x;
                 }
     }
-    // One 16-byte chunk (EPC couts of one pixel) at a time, so that the epilogue's temporaries -- not the K loop -- do not set
-    // the kernel's register allocation (whole-fragment temporaries + a full residual preload spilled 8-60 VGPRs at the 128
-    // of two workgroups per CU).  (fp16) the residual chunks of the next PD items are always in flight: without that the
-    // epilogue is a chain of dependent load -> store round trips (~1 us each under load, 3.8 us per workgroup in the block
-    // trace of conv_tap.hip) while the accumulators sit idle.  The cheap pixel decode is simply repeated.
+    // (fp16) every residual chunk of the wave is requested before the first one is used: the epilogue was a chain
+    // of TP dependent load -> store round trips (~1 us each under load, 3.8 us per workgroup in the block trace of
+    // conv_tap.hip) while the accumulators sat idle.  The cheap pixel decode is simply done twice.
     constexpr bool PRELOAD = sizeof(T) == 2;
-    constexpr int PD = PRELOAD ? (NI < 3 ? NI : 3) : 1;
-    uint4v rv[PD];
-    auto preload = [&](int i, uint4v &dst) {
-        int n, rem, oy, ox;
-        const bool ok = conv_decode_pixel<PADQ>(p, m_wave + (i / NCH) * 16 + fr, n, rem, oy, ox);
-        // pad / tail lanes read the first pixel's residual (always in range) and ignore it
-        const long long ro = ok ? (long long)n * p.res_img_stride + (long long)rem * p.res_ld : 0;
-        dst = *reinterpret_cast<const uint4v *>(reinterpret_cast<const T *>(p.res) + ro + cbase + (i % NCH) * EPC);
-    };
-    const bool pre = PRELOAD && p.has_res && p.vec_res;
-    if (pre) {
+    uint4v rv[PRELOAD ? TP : 1][PRELOAD ? CH / EPC : 1];
+    if (PRELOAD && p.has_res && p.vec_res) {
 #pragma unroll
-        for (int i = 0; i < PD; ++i) preload(i, rv[i]);
+        for (int b = 0; b < TP; ++b) {
+            int n, rem, oy, ox;
+            const bool ok = conv_decode_pixel<PADQ>(p, m_wave + b * 16 + fr, n, rem, oy, ox);
+            // pad / tail lanes read the first pixel's residual (always in range) and ignore it
+            const long long ro = ok ? (long long)n * p.res_img_stride + (long long)rem * p.res_ld : 0;
+            const T *rp = reinterpret_cast<const T *>(p.res) + ro + cbase;
+#pragma unroll
+            for (int q = 0; q < CH / EPC; ++q) rv[PRELOAD ? b : 0][PRELOAD ? q : 0] = *reinterpret_cast<const uint4v *>(rp + q * EPC);
+        }
     }
 
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
         int n, rem, oy, ox;
-        const bool okb = conv_decode_pixel<PADQ>(p, m_wave + b * 16 + fr, n, rem, oy, ox);
+        if (!conv_decode_pixel<PADQ>(p, m_wave + b * 16 + fr, n, rem, oy, ox)) continue;
+        float v[CH];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * a + j] = acc[a][b][j];
+        if (p.has_res) {
+            const T *rp = reinterpret_cast<const T *>(p.res) + (long long)n * p.res_img_stride + (long long)rem * p.res_ld + cbase;
+            if (p.vec_res) {
+#pragma unroll
+                for (int q = 0; q < CH / EPC; ++q) {
+                    const uint4v u = PRELOAD ? rv[PRELOAD ? b : 0][PRELOAD ? q : 0] : *reinterpret_cast<const uint4v *>(rp + q * EPC);
+                    T t[EPC];
+                    __builtin_memcpy(t, &u, 16);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) v[q * EPC + e] += (float)t[e];
+                }
+            } else {
+                for (int i = 0; i < nvalid; ++i) v[i] += (float)rp[i];
+            }
+        }
         long long off[4];
         int npos = 1;
         if (p.outmode == OUT_NORMAL) {
@@ -153,56 +167,35 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, float4v (&acc
             off[0] = (long long)n * p.out_img_stride + ((long long)(oy >> 1) * W2 + (ox >> 1)) * p.out_ld
                      + ((oy & 1) * 2 + (ox & 1)) * p.Cout + cbase;
         }
-        const T *rp = p.has_res ? reinterpret_cast<const T *>(p.res) + (long long)n * p.res_img_stride + (long long)rem * p.res_ld + cbase : nullptr;
+        if (p.out_f32) {
+            float *op = reinterpret_cast<float *>(p.out);
+            for (int q = 0; q < npos; ++q) {
+                if (p.vec_out) {
 #pragma unroll
-        for (int h = 0; h < NCH; ++h) {
-            const int i = b * NCH + h;
-            float v[EPC];
+                    for (int i = 0; i < CH / 4; ++i)
+                        *reinterpret_cast<float4v *>(op + off[q] + 4 * i) = float4v{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+                } else if (nvalid == CH) {
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) v[e] = acc[(h * EPC + e) >> 2][b][(h * EPC + e) & 3];
-            if (p.has_res) {
-                if (p.vec_res) {
-                    const uint4v u = PRELOAD ? rv[i % PD] : (okb ? *reinterpret_cast<const uint4v *>(rp + h * EPC) : uint4v{0u, 0u, 0u, 0u});
-                    T t[EPC];
-                    __builtin_memcpy(t, &u, 16);
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) v[e] += (float)t[e];
-                    if (pre && i + PD < NI) preload(i + PD, rv[i % PD]);       // refill the slot just consumed
-                } else if (okb) {
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e)
-                        if (h * EPC + e < nvalid) v[e] += (float)rp[h * EPC + e];
+                    for (int i = 0; i < CH; ++i) op[off[q] + i] = v[i];
+                } else {
+                    for (int i = 0; i < nvalid; ++i) op[off[q] + i] = v[i];
                 }
             }
-            if (!okb) continue;
-            if (p.out_f32) {
-                float *op = reinterpret_cast<float *>(p.out);
-                for (int q = 0; q < npos; ++q) {
-                    if (p.vec_out) {
+        } else {
+            T *op = reinterpret_cast<T *>(p.out);
+            T t[CH];
 #pragma unroll
-                        for (int k = 0; k < EPC / 4; ++k)
-                            *reinterpret_cast<float4v *>(op + off[q] + h * EPC + 4 * k) = float4v{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
-                    } else {
+            for (int i = 0; i < CH; ++i) t[i] = (T)v[i];
+            for (int q = 0; q < npos; ++q) {
+                if (p.vec_out) {
 #pragma unroll
-                        for (int e = 0; e < EPC; ++e)
-                            if (h * EPC + e < nvalid) op[off[q] + h * EPC + e] = v[e];
-                    }
-                }
-            } else {
-                T *op = reinterpret_cast<T *>(p.out);
-                T t[EPC];
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) t[e] = (T)v[e];
-                for (int q = 0; q < npos; ++q) {
-                    if (p.vec_out) {
+                    for (int i = 0; i < CH / EPC; ++i) {
                         uint4v u;
-                        __builtin_memcpy(&u, t, 16);
-                        *reinterpret_cast<uint4v *>(op + off[q] + h * EPC) = u;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < EPC; ++e)
-                            if (h * EPC + e < nvalid) op[off[q] + h * EPC + e] = t[e];
+                        __builtin_memcpy(&u, t + i * EPC, 16);
+                        *reinterpret_cast<uint4v *>(op + off[q] + i * EPC) = u;
                     }
+                } else {
+                    for (int i = 0; i < nvalid; ++i) op[off[q] + i] = t[i];
                 }
             }
         }

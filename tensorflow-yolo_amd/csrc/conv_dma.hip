@@ -337,15 +337,6 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
     return best;
 }
 
-// tiles per workgroup of a tap-reuse launch: a workgroup's tiles are cout tiles of ONE position tile (conv_tap.hip), so the
-// count divides the number of cout tiles; only the fp16 padded-linear tiles have the tile-loop instantiation
-int tap_tpw(int cfg, bool f32, int n_tiles_n, int requested) {
-    if (!is_tap_cfg(cfg) || !conv_tap_multi_ok(cfg - kFirstTapCfg, f32) || requested < 1) return 1;
-    int t = requested > n_tiles_n ? n_tiles_n : requested;
-    while (t > 1 && n_tiles_n % t) --t;
-    return t;
-}
-
 int dma_num_cfgs() { return kNumCfgs; }
 int dma_cfg_na(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg].na : 128; }
 int dma_cfg_bkc(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg].bkc : 8; }
@@ -389,8 +380,6 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
         if (qblocks <= 0 || qblocks > 0x7fffffffLL) return hipErrorInvalidValue;
         p.Mq = (int)mq;
         p.n_blocks = (int)qblocks;
-        p.tpw = tap_tpw(cfg, p.f32 != 0, p.n_tiles_n, p.tpw);
-        p.n_super = (p.n_blocks + p.tpw - 1) / p.tpw;
         conv_set_divisors(p, p.cin_chunks / k.bkc);
         // experiment: YOLO_CONV_TRACE=<file> appends, for every tap-reuse launch, a header {blocks, M, Cout, cin_chunks,
         // H, W, cfg, 0} and 8 uint64 per block (see the kernel); synchronous, for tools/trace_blocks.py only
@@ -431,8 +420,8 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
 }
 
 // the name rocprofv3's kernel trace prints for the kernel a tile id runs (yolo_kernel_info.symbol)
-const char *dma_cfg_symbol(int cfg, bool f32, bool multi) {
-    if (is_tap_cfg(cfg)) return conv_tap_symbol(cfg - kFirstTapCfg, f32, multi);
+const char *dma_cfg_symbol(int cfg, bool f32) {
+    if (is_tap_cfg(cfg)) return conv_tap_symbol(cfg - kFirstTapCfg, f32);
     switch (cfg) {
 #define X(id, ...) case id: return "void yolo::conv_igemm_dma_kernel<" #__VA_ARGS__ ">(yolo::ConvParams)";
         YOLO_DMA_VARIANTS(X)

@@ -61,8 +61,7 @@ __device__ __forceinline__ int tap_swz_w(int r) { return (0x78 >> (2 * ((r >> 2)
 // fragment pair: the exact fp32 FMA chain of conv.hip) -- the LDS geometry is in 16-byte chunks either way.
 // (F32 instead of the element type as template parameter: rocprofv3 does not demangle `_Float16` template arguments, and
 // yolo_kernel_info.symbol must be the name its kernel trace prints)
-// MULTI: the instantiation with the tile loop (tpw > 1); the single-tile one keeps its leaner register allocation.
-template <bool F32, int WM, int WN, int TM, int TP, int PRG, int OCC, int MODE, bool MULTI>
+template <bool F32, int WM, int WN, int TM, int TP, int PRG, int OCC, int MODE>
 __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams p) {
     typedef typename std::conditional<F32, float, _Float16>::type T;
     constexpr int NW = 8;
@@ -82,15 +81,8 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     static_assert(JA_TOT % NW == 0 || JA_TOT < NW, "weight tile must split evenly over the waves (or be smaller than them)");
     static_assert(MODE == 1 || PRG * 16 >= (NB / 16 + 2) * PW, "patch buffer too small for the 2-D tile");
     if constexpr (F32 && TP > 2) return;    // never launched (launch_conv_tap refuses): no registers for the second accumulator
-    if constexpr (MULTI && (F32 || MODE != 1 || TP < 3)) return;    // tile loop: fp16 padded-linear tiles of >= 192 positions only
-    // weight ring | two patch buffers | byte offset of every patch row (see setup: the per-lane patch offsets live here, not in
-    // four loop-carried VGPRs that the register allocator would otherwise spill -- with a vmcnt(0) at every reload)
-    // (tiles with >= 48 accumulator registers; the small-accumulator tiles keep the offsets in registers, and the 128 x 128
-    // tile has no LDS left at two workgroups per CU)
-    constexpr bool ROWTAB = TM * TP >= 12;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[S * A_BYTES + 2 * P_BYTES + (ROWTAB ? PRG * 16 * 4 : 0)];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[S * A_BYTES + 2 * P_BYTES];
     unsigned char *const smemP = smem + S * A_BYTES;
-    uint32_t *const rowoff = reinterpret_cast<uint32_t *>(smemP + 2 * P_BYTES);
 
     const int tid = threadIdx.x;
 #ifdef YOLO_EXPERIMENT      // block trace (tools/trace_blocks.py); not in the product build
@@ -101,91 +93,72 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    // A workgroup runs `tpw` consecutive tiles (tile = (position tile, cout tile), cout fastest; tpw divides the number of
-    // cout tiles, so they are cout tiles of ONE position tile): the patch offsets stay, the weight offsets advance by a
-    // constant, the patch is re-read from this CU's L1 / the XCD's L2, and the DMAs of the next tile's first stage are in
-    // flight while this tile's epilogue waits for its residual loads and drains its stores (below).
-    const int sb = xcd_remap(blockIdx.x, p.n_super);
-    int tile = sb * p.tpw;
-    const int tile_end = tile + p.tpw < p.n_blocks ? tile + p.tpw : p.n_blocks;
+    const int bid = xcd_remap(blockIdx.x, p.n_blocks);
+    const int mt = (int)fdiv((uint32_t)bid, p.dtiles_n);
+    const int nt = bid - mt * p.n_tiles_n;
+    const int n0 = nt * NA;
+    const int q0 = mt * NB;
     const bool has_a = JA_TOT % NW == 0 || wave < JA_TOT;   // wave-uniform
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wgt), 0, p.wgt_bytes, 0x00020000);
 
-    // ---- DMA geometry of one tile ----------------------------------------------------------------
+    // ---- DMA geometry ----------------------------------------------------------------------------
     const int lrow = lane >> 2;
+    uint32_t a_off[JA];
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+        const int r = (j * NW + wave) * 16 + lrow;              // LDS row of the weight tile
+        const int ws = r / (TM * 16), R = r % (TM * 16);
+        const int tm = R >> 4, g4 = (R >> 2) & 3, jj = R & 3;
+        const int ch = ws * (TM * 16) + g4 * CH + 4 * tm + jj;  // the cout that row holds (see conv_epilogue)
+        a_off[j] = (uint32_t)(n0 + ch) * p.wrow_bytes + (uint32_t)(((lane & 3) ^ tap_swz_w(lrow)) << 4);
+    }
     // patch row R <-> position q0 - (W+2) + R; row group g = j NW + wave
     // (the last of a wave's JP row groups may lie beyond the patch: waves >= JP_FULL issue one instruction fewer)
     constexpr int JP_FULL = PRG - (JP - 1) * NW;    // waves that own JP row groups
     const bool jp_full = wave < JP_FULL;            // wave-uniform
+    uint32_t b_off[JP];
     const uint32_t csw_p = (uint32_t)(((lane & 3) ^ (((lrow >> 2) & 1) << 1)) << 4);
-    int n0 = 0, q0 = 0;
-    uint32_t a_off[JA], b_off[ROWTAB ? 1 : JP];
-    auto setup = [&](int t) {
-        const int mt = (int)fdiv((uint32_t)t, p.dtiles_n);
-        const int nt = t - mt * p.n_tiles_n;
-        n0 = nt * NA;
-        q0 = mt * NB;
+    int t2_n = 0, t2_y0 = 0, t2_x0 = 0;     // MODE 2: image and first output pixel of this block's tile
+    if (MODE == 2) {
+        t2_n = (int)fdiv((uint32_t)mt, p.dqHW);             // qHW = tiles per image, qW = tiles per tile row
+        const int r = mt - t2_n * p.qHW;
+        const int ty = (int)fdiv((uint32_t)r, p.dqW);
+        t2_y0 = ty * (NB / 16);
+        t2_x0 = (r - ty * p.qW) * 16;
+    }
 #pragma unroll
-        for (int j = 0; j < JA; ++j) {
-            const int r = (j * NW + wave) * 16 + lrow;              // LDS row of the weight tile
-            const int ws = r / (TM * 16), R = r % (TM * 16);
-            const int tm = R >> 4, g4 = (R >> 2) & 3, jj = R & 3;
-            const int ch = ws * (TM * 16) + g4 * CH + 4 * tm + jj;  // the cout that row holds (see conv_epilogue)
-            a_off[j] = (uint32_t)(n0 + ch) * p.wrow_bytes + (uint32_t)(((lane & 3) ^ tap_swz_w(lrow)) << 4);
-        }
-        int t2_n = 0, t2_y0 = 0, t2_x0 = 0;     // MODE 2: image and first output pixel of this tile
+    for (int j = 0; j < JP; ++j) {
+        const int g = j * NW + wave;
+        bool ok;
+        int n, y, x;
         if (MODE == 2) {
-            t2_n = (int)fdiv((uint32_t)mt, p.dqHW);             // qHW = tiles per image, qW = tiles per tile row
-            const int r = mt - t2_n * p.qHW;
-            const int ty = (int)fdiv((uint32_t)r, p.dqW);
-            t2_y0 = ty * (NB / 16);
-            t2_x0 = (r - ty * p.qW) * 16;
+            const int R = g * 16 + lrow;
+            const int pr = R / PW, pc = R - pr * PW;
+            n = t2_n; y = t2_y0 - 1 + pr; x = t2_x0 - 1 + pc;
+            ok = g < PRG && pc < 18 && pr < NB / 16 + 2 && t2_n * p.HoWo < p.M && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        } else {
+            const int q = q0 - (p.qW + 1) + g * 16 + lrow;
+            ok = g < PRG && q >= 0 && q < p.Mq;
+            const int qq = ok ? q : 0;
+            n = (int)fdiv((uint32_t)qq, p.dqHW);
+            const int r = qq - n * p.qHW;
+            y = (int)fdiv((uint32_t)r, p.dqW);
+            x = r - y * p.qW;
+            ok = ok && x < p.W && y < p.H;
         }
-#pragma unroll
-        for (int j = 0; j < JP; ++j) {
-            const int g = j * NW + wave;
-            bool ok;
-            int n, y, x;
-            if (MODE == 2) {
-                const int R = g * 16 + lrow;
-                const int pr = R / PW, pc = R - pr * PW;
-                n = t2_n; y = t2_y0 - 1 + pr; x = t2_x0 - 1 + pc;
-                ok = g < PRG && pc < 18 && pr < NB / 16 + 2 && t2_n * p.HoWo < p.M && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-            } else {
-                const int q = q0 - (p.qW + 1) + g * 16 + lrow;
-                ok = g < PRG && q >= 0 && q < p.Mq;
-                const int qq = ok ? q : 0;
-                n = (int)fdiv((uint32_t)qq, p.dqHW);
-                const int r = qq - n * p.qHW;
-                y = (int)fdiv((uint32_t)r, p.dqW);
-                x = r - y * p.qW;
-                ok = ok && x < p.W && y < p.H;
-            }
-            const long long e = (long long)n * p.in_img_stride + ((long long)y * p.W + x) * p.in_ld + p.in_coff;
-            // the four lanes of a row differ only in the chunk (csw_p, added at issue time); a wave reads back only rows it
-            // wrote itself (row group g = j NW + wave), and LDS executes one wave's instructions in order: no barrier needed
-            const uint32_t off = ok ? (uint32_t)(e * (long long)sizeof(T)) : YOLO_INVALID_OFF;
-            if (ROWTAB) {
-                if ((lane & 3) == 0 && g < PRG) rowoff[g * 16 + lrow] = off;
-            } else {
-                b_off[ROWTAB ? 0 : j] = off;
-            }
-        }
-    };
+        const long long e = (long long)n * p.in_img_stride + ((long long)y * p.W + x) * p.in_ld + p.in_coff;
+        b_off[j] = ok ? (uint32_t)(e * (long long)sizeof(T)) + csw_p : YOLO_INVALID_OFF;
+    }
 
     const int C = p.cin_chunks >> 2;        // 32-channel slices
+    const int KT = 9 * C;
     auto issue_patch = [&](int c, int buf) {
         const uint32_t koff = (uint32_t)c * ROWB;
-        uint32_t ro[JP];
 #pragma unroll
         for (int j = 0; j < JP; ++j)
-            if (j + 1 < JP || jp_full) ro[j] = ROWTAB ? rowoff[(j * NW + wave) * 16 + lrow] : b_off[ROWTAB ? 0 : j];
-        // (an invalid row offset stays >= 2^31 with the chunk added: the range check still returns zeros)
-#pragma unroll
-        for (int j = 0; j < JP; ++j)
-            if (j + 1 < JP || jp_full) tap_dma16(rs_in, smemP + buf * P_BYTES + (j * NW + wave) * 1024, ro[j] + csw_p, koff);
+            if (j + 1 < JP || jp_full) tap_dma16(rs_in, smemP + buf * P_BYTES + (j * NW + wave) * 1024, b_off[j], koff);
     };
     auto issue_weights = [&](int tap, int c, int slot) {
         const uint32_t ka = (uint32_t)(tap * p.cin_chunks + 4 * c) * 16;
@@ -199,126 +172,93 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     // float32: second-level accumulator (conv_common.h: flush_acc); only the TP <= 2 tiles have the registers for it at
     // two workgroups per CU, so those are the float32 tiles (kTapF32)
     float4v acc2[F32 ? TM : 1][F32 ? TP : 1];
-
-    // ---- prologue of a tile: patch of slice 0, weights of taps 0 and 1 ------------------------------
-    auto prologue = [&]() {
-        issue_patch(0, 0);
-        issue_weights(0, 0, 0);
-        issue_weights(1, 0, 1);
-    };
-
-#ifdef YOLO_EXPERIMENT
-    const unsigned long long t_setup = p.trace ? wall_clock64() : 0ull;
-    unsigned long long t_loop = 0ull;
-#endif
-    setup(tile);
-    prologue();
-    for (;;) {
-        // Everything derived from the lane id below is recomputed per tile (the asm makes the value opaque, so the compiler
-        // cannot keep the fragment addresses alive across the epilogue, where registers are scarcest: 62 VGPRs spilled
-        // otherwise).  A dozen VALU instructions per tile.
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-    const int fr = ln & 15, fq = ln >> 4;
-        const int a_frag = (wm * TM * 16 + fr) * ROWB + (((fq ^ tap_swz_w(fr)) & 3) << 4);
-        const int rb = wn * TP * FROW + fr;     // patch row of this lane's position for tap (0, 0)
-
-        auto compute = [&](int slot, int buf, int shift) {
-            const unsigned char *A = smem + slot * A_BYTES + a_frag;
-            const int R = rb + shift;
-            const unsigned char *B = smemP + buf * P_BYTES + (R << 6) + ((fq << 4) ^ ((R & 4) << 3));
-            uint4v fa[TM], fb[TP];
 #pragma unroll
-            for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const uint4v *>(A + a * 16 * ROWB);
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < TP; ++b) fb[b] = *reinterpret_cast<const uint4v *>(B + b * FROW * ROWB);
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TP; ++b) acc[a][b] = mma_chunk<T>(fa[a], fb[b], acc[a][b]);
-        };
+        for (int b = 0; b < TP; ++b) {
+            acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
+            if (F32) acc2[F32 ? a : 0][F32 ? b : 0] = float4v{0.f, 0.f, 0.f, 0.f};
+        }
 
-    // one 32-channel slice; the patch buffer index is a compile-time constant (LDS immediates, no address registers)
-        auto run_slice = [&](int c, auto bufc) {
-            constexpr int buf = decltype(bufc)::value;
-            const bool more = c + 1 < C;        // a next slice exists: its patch is fetched during this one
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                // Wait for the weights of this tap.  Issue order per tap: weights(tap+2), then (tap 0 only) the next
-                // patch; younger than weights(tap) are weights(tap+1) and, at taps 1 and 2, that patch.  (In the first
-                // slice of a tile that follows another one, the previous epilogue's loads and stores are younger still:
-                // the counted waits then cover some of those as well -- stricter, never weaker.)
-                const bool last = !more && tap == 8;
-                const bool with_patch = more && (tap == 1 || tap == 2);
-                if (last) tap_wait_vm<0>();
-                else if (has_a) {
-                    if (!with_patch) tap_wait_vm<JA>();
-                    else if (jp_full) tap_wait_vm<JA + JP>();
-                    else tap_wait_vm<JA + JP - 1>();
-                } else {            // this wave issues patch instructions only
-                    if (!with_patch) tap_wait_vm<0>();
-                    else if (jp_full) tap_wait_vm<JP>();
-                    else tap_wait_vm<JP - 1>();
-                }
-                // Nothing is scheduled across the barrier: every ds_read of this tap is consumed by an MFMA before the wave
-                // arrives, so a slot is provably idle when another wave's DMA (issued after the barrier) overwrites it.
-                // (The compiler otherwise sinks the last fragment reads + MFMAs below the barrier: 0.5 % faster, but safe
-                // only by timing.)
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                {   // weights two taps ahead
-                    const int t2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;
-                    const int c2 = tap + 2 < 9 ? c : c + 1;
-                    if (c2 < C) issue_weights(t2, c2, (tap + 2) % S);
-                }
-                if (tap == 0 && more) issue_patch(c + 1, buf ^ 1);
-                const int kh = tap / 3, kw = tap - 3 * kh;
-                compute(tap % S, buf, MODE == 2 ? kh * PW + kw : kh * p.qW + kw);
-            }
-        };
+    const int fr = lane & 15, fq = lane >> 4;
+    const int a_frag = (wm * TM * 16 + fr) * ROWB + (((fq ^ tap_swz_w(fr)) & 3) << 4);
+    const int rb = wn * TP * FROW + fr;     // patch row of this lane's position for tap (0, 0)
 
+    auto compute = [&](int slot, int buf, int shift) {
+        const unsigned char *A = smem + slot * A_BYTES + a_frag;
+        const int R = rb + shift;
+        const unsigned char *B = smemP + buf * P_BYTES + (R << 6) + ((fq << 4) ^ ((R & 4) << 3));
+        uint4v fa[TM], fb[TP];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const uint4v *>(A + a * 16 * ROWB);
+#pragma unroll
+        for (int b = 0; b < TP; ++b) fb[b] = *reinterpret_cast<const uint4v *>(B + b * FROW * ROWB);
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < TP; ++b) {
-                acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
-                if (F32) acc2[F32 ? a : 0][F32 ? b : 0] = float4v{0.f, 0.f, 0.f, 0.f};
-            }
-        for (int c = 0; c < C; c += 2) {
-            run_slice(c, std::integral_constant<int, 0>());
-            if (c + 1 < C) run_slice(c + 1, std::integral_constant<int, 1>());
-            if constexpr (F32) flush_acc<TM, TP>(acc, acc2);        // two 16-channel slices x 9 taps = 288 k per chain
-        }
-        if constexpr (F32) {
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TP; ++b) acc[a][b] = acc2[a][b];
-        }
+            for (int b = 0; b < TP; ++b) acc[a][b] = mma_chunk<T>(fa[a], fb[b], acc[a][b]);
+    };
+
+    // ---- prologue: patch of slice 0, weights of taps 0 and 1 --------------------------------------
 #ifdef YOLO_EXPERIMENT
-        t_loop = p.trace ? wall_clock64() : 0ull;
+    const unsigned long long t_setup = p.trace ? wall_clock64() : 0ull;
 #endif
-        // The next tile's first stage goes out BEFORE this tile's epilogue.  LDS: with an even slice count the last slice
-        // read patch buffer 1, and buffer 0 was last read nine or more barriers ago; weight slots 0 and 1 were last read at
-        // taps 6 and 7, and every wave has passed the barrier of tap 8 (no ds_read crosses a barrier, above).  With an odd
-        // slice count the last slice read buffer 0: the prologue then waits for a barrier behind the epilogue.
-        const int n0c = n0, q0c = q0;
-        const bool more_tiles = MULTI && tile + 1 < tile_end;       // workgroup-uniform
-        if (more_tiles) {                                   // next cout tile of the same position tile
-            n0 += NA;
+    issue_patch(0, 0);
+    issue_weights(0, 0, 0);
+    issue_weights(1, 0, 1);
+
+    // one 32-channel slice; the patch buffer index is a compile-time constant (LDS immediates, no address registers)
+    auto run_slice = [&](int c, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        const bool more = c + 1 < C;        // a next slice exists: its patch is fetched during this one
 #pragma unroll
-            for (int j = 0; j < JA; ++j) a_off[j] += (uint32_t)NA * p.wrow_bytes;
-            if (!(C & 1)) prologue();
-        }
-        conv_epilogue<T, TM, TP, MODE>(p, acc, n0c + wm * (TM * 16) + fq * CH, q0c + wn * (TP * 16), fr);
-        if (!more_tiles) break;
-        if (C & 1) {
+        for (int tap = 0; tap < 9; ++tap) {
+            // Wait for the weights of this tap.  Issue order per tap: weights(tap+2), then (tap 0 only) the next
+            // patch; younger than weights(tap) are weights(tap+1) and, at taps 1 and 2, that patch.
+            const bool last = !more && tap == 8;
+            const bool with_patch = more && (tap == 1 || tap == 2);
+            if (last) tap_wait_vm<0>();
+            else if (has_a) {
+                if (!with_patch) tap_wait_vm<JA>();
+                else if (jp_full) tap_wait_vm<JA + JP>();
+                else tap_wait_vm<JA + JP - 1>();
+            } else {            // this wave issues patch instructions only
+                if (!with_patch) tap_wait_vm<0>();
+                else if (jp_full) tap_wait_vm<JP>();
+                else tap_wait_vm<JP - 1>();
+            }
+            // Nothing is scheduled across the barrier: every ds_read of this tap is consumed by an MFMA before the wave
+            // arrives, so a slot is provably idle when another wave's DMA (issued after the barrier) overwrites it.
+            // (The compiler otherwise sinks the last fragment reads + MFMAs below the barrier: 0.5 % faster, but safe
+            // only by timing.)
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
-            prologue();
+            {   // weights two taps ahead
+                const int t2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;
+                const int c2 = tap + 2 < 9 ? c : c + 1;
+                if (c2 < C) issue_weights(t2, c2, (tap + 2) % S);
+            }
+            if (tap == 0 && more) issue_patch(c + 1, buf ^ 1);
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            compute(tap % S, buf, MODE == 2 ? kh * PW + kw : kh * p.qW + kw);
         }
-        ++tile;
+    };
+    for (int c = 0; c < C; c += 2) {
+        run_slice(c, std::integral_constant<int, 0>());
+        if (c + 1 < C) run_slice(c + 1, std::integral_constant<int, 1>());
+        if constexpr (F32) flush_acc<TM, TP>(acc, acc2);        // two 16-channel slices x 9 taps = 288 k per chain
     }
+    if constexpr (F32) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TP; ++b) acc[a][b] = acc2[a][b];
+    }
+    (void)KT;
+#ifdef YOLO_EXPERIMENT
+    const unsigned long long t_loop = p.trace ? wall_clock64() : 0ull;
+#endif
+    conv_epilogue<T, TM, TP, MODE>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
 #ifdef YOLO_EXPERIMENT
     if (p.trace && tid == 0) {          // YOLO_CONV_TRACE: phase timestamps (100 MHz) + placement of wave 0 of every block
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -326,7 +266,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         r[0] = t_start; r[1] = t_setup; r[2] = t_loop; r[3] = wall_clock64();
         r[4] = __builtin_amdgcn_s_getreg(0xF804);      // HW_ID
         r[5] = __builtin_amdgcn_s_getreg(0xF814);      // XCC_ID
-        r[6] = (unsigned long long)tile;
+        r[6] = (unsigned long long)bid;
         r[7] = (unsigned long long)clock64() - c_start;     // shader-clock cycles of the block (vs r[3] - r[0] at 100 MHz)
     }
 #endif
@@ -356,13 +296,10 @@ bool conv_tap_fits(int variant, int W) {
     X(4, 2, 4, 4, 4, 27, 4, 2) \
     X(5, 1, 8, 4, 2, 27, 4, 2)
 
-bool conv_tap_multi_ok(int variant, bool f32) { return !f32 && variant >= 0 && variant <= 2; }
-
-const char *conv_tap_symbol(int variant, bool f32, bool multi) {
+const char *conv_tap_symbol(int variant, bool f32) {
     switch (variant) {
-#define X(id, ...) case id: return f32 ? "void yolo::conv3x3_tap_kernel<true, " #__VA_ARGS__ ", false>(yolo::ConvParams)" \
-                                 : multi ? "void yolo::conv3x3_tap_kernel<false, " #__VA_ARGS__ ", true>(yolo::ConvParams)" \
-                                         : "void yolo::conv3x3_tap_kernel<false, " #__VA_ARGS__ ", false>(yolo::ConvParams)";
+#define X(id, ...) case id: return f32 ? "void yolo::conv3x3_tap_kernel<true, " #__VA_ARGS__ ">(yolo::ConvParams)" \
+                                       : "void yolo::conv3x3_tap_kernel<false, " #__VA_ARGS__ ">(yolo::ConvParams)";
         YOLO_TAP_VARIANTS(X)
 #undef X
     default: return "";
@@ -373,14 +310,11 @@ hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
     if (p.ksize != 3 || p.stride != 1 || p.pad != 1 || p.Ho != p.H || p.Wo != p.W || (p.cin_chunks & 3) || !conv_tap_fits(variant, p.W) ||
         (p.f32 && !conv_tap_f32_ok(variant)))
         return hipErrorInvalidValue;
-    if (p.tpw < 1 || p.n_super != (p.n_blocks + p.tpw - 1) / p.tpw || (p.tpw > 1 && !conv_tap_multi_ok(variant, p.f32 != 0)))
-        return hipErrorInvalidValue;
-    const dim3 grid((unsigned)p.n_super);
+    const dim3 grid((unsigned)p.n_blocks);
     switch (variant) {
 #define X(id, ...) case id: \
-        if (p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<true, __VA_ARGS__, false>), grid, dim3(512), 0, s, p); \
-        else if (p.tpw > 1) hipLaunchKernelGGL((conv3x3_tap_kernel<false, __VA_ARGS__, true>), grid, dim3(512), 0, s, p); \
-        else hipLaunchKernelGGL((conv3x3_tap_kernel<false, __VA_ARGS__, false>), grid, dim3(512), 0, s, p); \
+        if (p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<true, __VA_ARGS__>), grid, dim3(512), 0, s, p); \
+        else hipLaunchKernelGGL((conv3x3_tap_kernel<false, __VA_ARGS__>), grid, dim3(512), 0, s, p); \
         break;
         YOLO_TAP_VARIANTS(X)
 #undef X

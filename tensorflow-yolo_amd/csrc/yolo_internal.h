@@ -87,7 +87,6 @@ struct ConvParams {
     int leaky, has_res, outmode, out_f32, vec_out, vec_res;
     int f32;                   // elements of input / weights / residual are float32 (else fp16)
     int n_tiles_n, n_blocks;
-    int tpw, n_super;          // conv_tap.hip: consecutive tiles one workgroup runs, workgroups = ceil(n_blocks / tpw)
     int dbg;                   // experiment flags (YOLO_CONV_DBG): 1 skip steady-state DMA, 2 skip MFMA phase
     int qW, qHW, Mq;           // conv_tap.hip: padded-linear pixel grid, row stride W+1, image stride (H+1)(W+1), total
     float *obj_out;            // head convs (staged float32 epilogue): compact objectness logits [B][obj_rows] or null
@@ -222,10 +221,8 @@ bool conv_tap_f32_ok(int variant);            // float32 instantiation usable (t
 bool dma_cfg_f32_ok(int cfg);
 const char *dma_cfg_name(int cfg);
 // names exactly as rocprofv3's kernel trace prints them (yolo_kernel_info.symbol: joins bench.py's roofline to profiles/*.csv)
-const char *dma_cfg_symbol(int cfg, bool f32, bool multi);
-const char *conv_tap_symbol(int variant, bool f32, bool multi);
-bool conv_tap_multi_ok(int variant, bool f32);     // the tile-loop instantiation exists (tpw > 1 allowed)
-int tap_tpw(int cfg, bool f32, int n_tiles_n, int requested);      // tiles per workgroup a tap-reuse launch will use
+const char *dma_cfg_symbol(int cfg, bool f32);
+const char *conv_tap_symbol(int variant, bool f32);
 std::string conv_symbol(int dtype, int cfg, bool perchunk);
 std::string first_symbol(int dtype, int cout, bool pool);
 std::string aux_symbol(int kind, int dtype, bool vec);

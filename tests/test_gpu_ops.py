@@ -25,10 +25,10 @@ def oracle_out(net, w, x, dtype, keep=None):
     return FR.forward(L, w, x, keep=keep, storage="fp16" if dtype == "fp16" else None)
 
 
-def check_graph(net, x, dtype, seed=0, read=(), max_batch=None, tile=None, tpw=0):
+def check_graph(net, x, dtype, seed=0, read=(), max_batch=None, tile=None):
     w = synth.darknet_stream(net, seed=seed)
     want, kept = oracle_out(net, w, x, dtype, keep=set(read))
-    got, eng = run_hip(net, w, x, dtype, keep_all=bool(read), max_batch=max_batch, force_tile=tile, tap_tpw=tpw)
+    got, eng = run_hip(net, w, x, dtype, keep_all=bool(read), max_batch=max_batch, force_tile=tile)
     assert got.shape == want.shape, (got.shape, want.shape)
     errs = {"final": rel_err(got, want)}
     for i in read:
@@ -318,27 +318,3 @@ def test_every_dma_tile_config(tile):
     eng = check_graph(g, x, "fp16", seed=3, read=(2, 5, 7, 10), tile=tile)
     names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
     assert "conv_igemm_dma" in names
-
-
-@pytest.mark.parametrize("tile,tpw", [(8, 2), (8, 4), (9, 2), (9, 4), (10, 2), (10, 3), (10, 4)])
-def test_tap_reuse_several_tiles_per_workgroup(tile, tpw):
-    """conv_tap.hip's tile loop (yolo_net_options.tap_tpw): a workgroup runs 2..4 cout tiles of one position tile, the next
-    tile's first DMAs in flight under the epilogue -- Cout 256 / 384 / 512 / 1024 (2, 3, 4, 8 tiles of 128; 1, 2, 4 of 256: a count
-    that does not divide falls back to the largest divisor), even and odd slice counts (Cin 128, 256 / 96, 160), residual,
-    position tails, several images"""
-    g = new_graph(19, 21, 3)
-    g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))                  # 1
-    g.append(PL.conv2d_bn_act(g[-1].out, 128, 1, 1))                 # 2
-    g.append(PL.conv2d_bn_act(g[-1].out, 256, 3, 1))                 # 3  Cin 128: 4 slices, 2 cout tiles
-    g.append(PL.conv2d_bn_act(g[-1].out, 96, 1, 1))                  # 4
-    g.append(PL.conv2d_bn_act(g[-1].out, 256, 3, 1))                 # 5  Cin 96: 3 slices (odd: prologue behind a barrier)
-    g.append(PL.shortcut(g[-1].out, g[-3].out))                      # 6  fused residual
-    g.append(PL.conv2d_bn_act(g[-1].out, 512, 3, 1))                 # 7  Cin 256: 8 slices, 4 cout tiles
-    g.append(PL.conv2d_bn_act(g[-1].out, 160, 1, 1))                 # 8
-    g.append(PL.conv2d_bn_act(g[-1].out, 384, 3, 1))                 # 9  Cin 160: 5 slices, 3 cout tiles
-    g.append(PL.conv2d_bn_act(g[-1].out, 1024, 3, 1))                # 10 8 cout tiles (4 of 256)
-    g.append(PL.conv2d_bn_act(g[-1].out, 255, 1, 1, use_batch_normalization=False, activation_fn="linear"))
-    x = synth.synthetic_input(3, 19, 21, 3, seed=14)
-    eng = check_graph(g, x, "fp16", seed=6, read=(3, 6, 7, 9, 10), tile=tile, tpw=tpw)
-    syms = " ".join(ki.symbol.decode() for ki in eng.kernel_infos())
-    assert ", true>(yolo::ConvParams)" in syms, syms                 # the tile-loop instantiation is what ran
