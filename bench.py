@@ -50,7 +50,7 @@ VOC_TINY = [1.08, 1.19, 3.42, 4.41, 6.63, 11.38, 9.42, 5.11, 16.62, 10.52]
 COCO_V3 = [10, 13, 16, 30, 33, 23, 30, 61, 62, 45, 59, 119, 116, 90, 156, 198, 373, 326]
 
 
-def make_model(kind, size, batch, dtype, seed=0, streams=0, max_boxes=256):
+def make_model(kind, size, batch, dtype, seed=0, streams=0, max_boxes=256, **engine_kw):
     from tensorflow_yolo_amd import YoloV2, YoloV2Tiny, YoloV3
     from tensorflow_yolo_amd.net import synth
     cls, anchors, ncls = {"v3": (YoloV3, COCO_V3, 80), "v2": (YoloV2, COCO_V2, 80), "v2-tiny": (YoloV2Tiny, VOC_TINY, 20)}[kind]
@@ -59,7 +59,7 @@ def make_model(kind, size, batch, dtype, seed=0, streams=0, max_boxes=256):
     net = cls.create_network(np.reshape(anchors, [-1, 2]), names, False, input_shape=(size, size, 3))
     hg, frac = synth.HEAD_DEFAULTS[kind]
     w = synth.darknet_stream(net, seed=seed, num_classes=ncls, head_gain=hg, obj_bias=0.0)
-    model.build(anchors, names, (size, size, 3), dtype=dtype, max_batch=batch, weights=w, streams=streams, max_boxes=max_boxes)
+    model.build(anchors, names, (size, size, 3), dtype=dtype, max_batch=batch, weights=w, streams=streams, max_boxes=max_boxes, **engine_kw)
     # data-dependent objectness prior (uses the product's own forward): a realistic handful of candidates
     w = synth.calibrate_model(model, synth.synthetic_input(min(batch, 2), size, size, 3, seed=999), frac)
     return model, w, anchors, ncls
@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--workload", default="v3-608-b32-fp16", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the 2-image parity check against the CPU oracle")
+    ap.add_argument("--force-tile", type=int, default=None, help="tuning hook: yolo_net_options.force_tile (one conv tile id wherever valid)")
     ap.add_argument("--max-boxes", type=int, default=256, help="box records per image (SURVEY 8e: K_max = 256 -> 196.7 KB per rank)")
     ap.add_argument("--autotune", action="store_true", help="time every conv tile per layer on the device first (default: built-in rules)")
     ap.add_argument("--streams", type=int, default=0, help="run every batch as this many independent parts on as many HIP streams "
@@ -193,7 +194,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     kind, size, batch, dtype = WORKLOADS[args.workload]
-    model, w, anchors, ncls = make_model(kind, size, batch, dtype, streams=args.streams, max_boxes=args.max_boxes)
+    model, w, anchors, ncls = make_model(kind, size, batch, dtype, streams=args.streams, max_boxes=args.max_boxes, force_tile=args.force_tile)
     eng = model.net.engine
     from tensorflow_yolo_amd.net import synth
     # two different resident input batches, alternated, so no step re-reads the previous step's input
