@@ -230,11 +230,61 @@ bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile) {
     return dma_eligible(net, k) && dma_cfg_valid(tile, k.cout, k.cpt, true, k.ksize, k.stride, k.in.W);
 }
 
+// Split-K decision for one conv launch (0 = the 4-wave kernel with the planner's cfg, else a tap-reuse tile): when the launch
+// would leave most of the chip idle (<= 128 workgroups) and K is long, the K range is cut into `ks` splits of `ku` units
+// (conv_tap.hip: channel slices, conv.hip: K tiles) so that ~384 workgroups exist; their float32 partial sums meet in
+// splitk_reduce_kernel.  Returns 1 when the launch stays whole.
+int choose_ksplit(const yolo_net *net, const Kernel &k, const ConvParams &p, int tile, int &ku) {
+    ku = 0;
+    if (!net->splitk_bytes || p.M <= 0) return 1;
+    long long blocks;
+    int units, min_units;
+    if (tile == 0) {
+        const int na = k.cfg == CFG_N128 ? 128 : k.cfg == CFG_N64 ? 64 : 32, nb = k.cfg == CFG_N128 ? 128 : 256;
+        blocks = ((long long)p.M + nb - 1) / nb * ((p.Cout + na - 1) / na);
+        units = p.ktiles;
+        min_units = 8;                  // >= 256 (float32) / 512 (fp16) k per split
+    } else if (dma_cfg_is_tap(tile) && dma_cfg_splitk_ok(tile)) {
+        const long long mq = (long long)(p.M / p.HoWo) * (p.H + 1) * (p.W + 1);        // padded-linear positions
+        blocks = (mq + dma_cfg_nb(tile) - 1) / dma_cfg_nb(tile) * ((p.Cout + dma_cfg_na(tile) - 1) / dma_cfg_na(tile));
+        units = p.cin_chunks >> 2;
+        min_units = 2;                  // >= 288 (float32) / 576 (fp16) k per split
+    } else {
+        return 1;
+    }
+    if (blocks > 128 || units < 2 * min_units) return 1;
+    long long ks = 384 / blocks;
+    if (ks > units / min_units) ks = units / min_units;
+    if (ks > 32) ks = 32;
+    const size_t cout_pad = ((size_t)p.Cout + 127) / 128 * 128;
+    while (ks >= 2 && (size_t)ks * (size_t)p.M * cout_pad * 4 > net->splitk_bytes) --ks;
+    if (ks < 2) return 1;
+    ku = (int)((units + ks - 1) / ks);
+    return (units + ku - 1) / ku;       // every split owns at least one unit
+}
+
 // tile < 0: heuristic (choose_dma_cfg); 0: 4-wave kernel of conv.hip; > 0: conv_dma.hip tile id
-hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParams &p, int tile, hipStream_t s) {
+hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParams &p0, int tile, hipStream_t s) {
     if (!dma_eligible(net, k) || (tile > 0 && !conv_tile_valid(net, k, tile))) tile = 0;
-    else if (tile < 0) tile = choose_dma_cfg(p.M, k.cout, k.cpt, p.taps, k.has_res, true, k.stride, k.in.W, net->opt.dtype == YOLO_DTYPE_F32);
-    return tile > 0 ? launch_conv_dma(p, tile, s) : launch_conv(p, net->opt.dtype, k.cfg, k.perchunk != 0, s);
+    else if (tile < 0) tile = choose_dma_cfg(p0.M, k.cout, k.cpt, p0.taps, k.has_res, true, k.stride, k.in.W, net->opt.dtype == YOLO_DTYPE_F32);
+    ConvParams p = p0;
+    int ku = 0;
+    const int ks = choose_ksplit(net, k, p, tile, ku);
+    if (ks > 1) {
+        p.ksplit = ks; p.kunits = ku;
+        p.cout_pad = (p.Cout + 127) / 128 * 128;
+        p.part = reinterpret_cast<float *>(net->dev_ws + net->splitk_off);
+    }
+    hipError_t e = tile > 0 ? launch_conv_dma(p, tile, s) : launch_conv(p, net->opt.dtype, k.cfg, k.perchunk != 0, s);
+    if (e != hipSuccess || ks <= 1) return e;
+    ReduceParams r;
+    memset(&r, 0, sizeof r);
+    r.part = p.part; r.bias = p.bias; r.res = p.has_res ? p.res : nullptr; r.out = p.out;
+    r.obj_out = p.obj_out; r.obj_width = p.obj_width; r.obj_rows = p.obj_rows; r.obj_row0 = p.obj_row0; r.obj_na = p.obj_na;
+    r.ksplit = ks; r.M = p.M; r.Cout = p.Cout; r.cout_pad = p.cout_pad; r.HoWo = p.HoWo; r.Wo = p.Wo;
+    r.out_ld = p.out_ld; r.res_ld = p.res_ld; r.leaky = p.leaky; r.outmode = p.outmode; r.out_f32 = p.out_f32; r.f32 = p.f32;
+    r.out_img_stride = p.out_img_stride; r.res_img_stride = p.res_img_stride;
+    return launch_splitk_reduce(r, s);
 }
 
 int run_forward_pass(yolo_net *net, const float *in_dev, int batch, float *out_dev, hipStream_t s, hipEvent_t *ev, int img0, int arena,

@@ -211,6 +211,75 @@ hipError_t launch_eltwise(const EltParams &p, int dtype, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Split-K second pass: out = epilogue(sum over the K splits of the raw float32 accumulators), with the epilogue semantics of
+// conv_common.h: + folded-BN bias -> leaky 0.1 -> + residual (no activation after the add) -> output index map (identity /
+// nearest-upsample x2 / block-major reorg) -> T or float32; head convs also fill the compact objectness array.  One thread per
+// (pixel, 4 couts); the slabs are a few MB and L2-resident.
+template <bool F32>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const ReduceParams p) {
+    typedef typename std::conditional<F32, float, _Float16>::type T;
+    typedef float float4v __attribute__((ext_vector_type(4)));
+    const int groups = p.cout_pad >> 2;
+    const long long total = (long long)p.M * groups;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int m = (int)(idx / groups);
+        const int c = (int)(idx - (long long)m * groups) * 4;
+        if (c >= p.Cout) continue;
+        const float *src = p.part + (size_t)m * p.cout_pad + c;
+        float4v a = *reinterpret_cast<const float4v *>(src);
+        for (int s = 1; s < p.ksplit; ++s) a += *reinterpret_cast<const float4v *>(src + (size_t)s * p.M * p.cout_pad);
+        const int n = m / p.HoWo, rem = m - n * p.HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        float v[4] = {a.x, a.y, a.z, a.w};
+        const int nv = p.Cout - c < 4 ? p.Cout - c : 4;
+        for (int i = 0; i < nv; ++i) {
+            const float x = v[i] + p.bias[c + i];
+            v[i] = p.leaky ? fmaxf(0.1f * x, x) : x;
+        }
+        if (p.res) {
+            const T *rp = reinterpret_cast<const T *>(p.res) + (long long)n * p.res_img_stride + (long long)rem * p.res_ld + c;
+            for (int i = 0; i < nv; ++i) v[i] += (float)rp[i];
+        }
+        long long off[4];
+        int npos = 1;
+        if (p.outmode == OUT_NORMAL) {
+            off[0] = (long long)n * p.out_img_stride + (long long)rem * p.out_ld + c;
+        } else if (p.outmode == OUT_UP2) {
+            const long long W2 = 2LL * p.Wo;
+            const long long base = (long long)n * p.out_img_stride + ((2LL * oy) * W2 + 2LL * ox) * p.out_ld + c;
+            off[0] = base; off[1] = base + p.out_ld; off[2] = base + W2 * p.out_ld; off[3] = base + (W2 + 1) * p.out_ld;
+            npos = 4;
+        } else {
+            const int W2 = p.Wo >> 1;
+            off[0] = (long long)n * p.out_img_stride + ((long long)(oy >> 1) * W2 + (ox >> 1)) * p.out_ld + ((oy & 1) * 2 + (ox & 1)) * p.Cout + c;
+        }
+        for (int q = 0; q < npos; ++q) {
+            if (p.out_f32) {
+                float *op = reinterpret_cast<float *>(p.out) + off[q];
+                for (int i = 0; i < nv; ++i) op[i] = v[i];
+            } else {
+                T *op = reinterpret_cast<T *>(p.out) + off[q];
+                for (int i = 0; i < nv; ++i) op[i] = (T)v[i];
+            }
+        }
+        if (p.obj_out) {
+            for (int i = 0; i < nv; ++i) {
+                const int a_ = (c + i) / p.obj_width;
+                if (c + i - a_ * p.obj_width == 4) p.obj_out[n * p.obj_rows + p.obj_row0 + rem * p.obj_na + a_] = v[i];
+            }
+        }
+    }
+}
+
+hipError_t launch_splitk_reduce(const ReduceParams &p, hipStream_t s) {
+    if (p.ksplit < 2 || !p.part || (p.cout_pad & 3) || p.M <= 0) return hipErrorInvalidValue;
+    const dim3 g(grid_for((long long)p.M * (p.cout_pad >> 2))), b(256);
+    if (p.f32) hipLaunchKernelGGL(splitk_reduce_kernel<true>, g, b, 0, s, p);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<false>, g, b, 0, s, p);
+    return hipGetLastError();
+}
+
 // the names rocprofv3's kernel trace prints (yolo_kernel_info.symbol)
 std::string aux_symbol(int kind, int dtype, bool vec) {
     const char *f = dtype == YOLO_DTYPE_F16 ? "false" : "true";

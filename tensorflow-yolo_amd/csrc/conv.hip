@@ -158,16 +158,19 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams p) 
     };
 
     // ---- main loop ------------------------------------------------------------------------
-    load_tile(0);
+    // K tiles of this workgroup: all of them, or one K split's share (split-K, blockIdx.y)
+    const int kt0 = p.ksplit > 1 ? (int)blockIdx.y * p.kunits : 0;
+    const int kt1 = p.ksplit > 1 ? (kt0 + p.kunits < p.ktiles ? kt0 + p.kunits : p.ktiles) : p.ktiles;
+    load_tile(kt0);
     store_tile(0);
     __syncthreads();
-    for (int kt = 0; kt < p.ktiles; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < p.ktiles;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        const bool more = kt + 1 < kt1;
         if (more) load_tile(kt + 1);
         compute(cur);
         if constexpr (F32) {            // a K tile is 32 floats deep: restart the chain every 256 k
-            if ((kt & 7) == 7 || !more) flush_acc<TM, TP>(acc, acc2);
+            if (((kt - kt0) & 7) == 7 || !more) flush_acc<TM, TP>(acc, acc2);
         }
         if (more) store_tile(cur ^ 1);
         __syncthreads();
@@ -179,6 +182,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams p) 
             for (int b = 0; b < TP; ++b) acc[a][b] = acc2[a][b];
     }
 
+    if (p.ksplit > 1) {     // split-K: raw accumulators to the float32 slab, epilogue in splitk_reduce_kernel
+        conv_store_partial<TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH, m0 + wn * (TP * 16), fr, (int)blockIdx.y);
+        return;
+    }
     // ---- epilogue: bias, leaky, residual, store (conv_common.h) -------------------------------
     if (p.out_f32 && !p.vec_out && p.outmode == OUT_NORMAL && !p.has_res) {      // head conv: coalesced float32 rows via LDS
         static_assert(4 * 16 * kStagePitch(TM) * 4 <= 2 * TILE_BYTES, "staging slabs must fit in the tile buffers");
@@ -205,7 +212,8 @@ static hipError_t launch_cfg(const ConvParams &p0, int cfg, hipStream_t s) {
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     p.n_blocks = (int)blocks;
     conv_set_divisors(p, p.tiles_per_tap);
-    dim3 grid((unsigned)blocks), block(256);
+    if (p.ksplit > 1 && (!p.part || p.kunits < 1 || (long long)p.ksplit * p.kunits < p.ktiles)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)blocks, (unsigned)(p.ksplit > 1 ? p.ksplit : 1)), block(256);
     switch (cfg) {
     case CFG_N128: hipLaunchKernelGGL((conv_igemm_kernel<F32, 2, 2, 4, 4, PC>), grid, block, 0, s, p); break;
     case CFG_N64: hipLaunchKernelGGL((conv_igemm_kernel<F32, 1, 4, 4, 4, PC>), grid, block, 0, s, p); break;

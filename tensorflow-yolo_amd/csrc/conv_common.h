@@ -202,6 +202,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, float4v (&acc
     }
 }
 
+// Split-K: the wave's raw accumulators (no bias, no activation) go to the float32 slab part[split][pixel][cout_pad]; a lane
+// owns CH contiguous couts of a pixel -> 16-byte stores, 64 contiguous bytes per lane and fragment.
+template <int TM, int TP, int PADQ = 0>
+__device__ __forceinline__ void conv_store_partial(const ConvParams &p, float4v (&acc)[TM][TP], int cbase, int m_wave, int fr, int split) {
+    if (cbase >= p.cout_pad) return;
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+        int n, rem, oy, ox;
+        if (!conv_decode_pixel<PADQ>(p, m_wave + b * 16 + fr, n, rem, oy, ox)) continue;
+        float *dst = p.part + ((size_t)split * (size_t)p.M + (size_t)(n * p.HoWo + rem)) * (size_t)p.cout_pad + cbase;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) *reinterpret_cast<float4v *>(dst + 4 * a) = acc[a][b];
+    }
+}
+
 // Head convs: float32 output with a channel count that is not a multiple of 4 (255 = 3 x 85, 425 = 5 x 85), so the
 // generic epilogue falls back to one scattered 4-byte store per value (64 lanes -> 64 different 4-byte pieces per
 // instruction).  Here each wave transposes its 16 pixels x (4 CH) couts through a private LDS slab and writes every

@@ -241,12 +241,14 @@ static const DmaCfg kCfgs[] = {
     {128, 256, 2, 1.00f, "128x256,tap9,2d,x2", 4},     // 12: 2-D 16x16 tiles for maps wider than 78
     {64, 256, 2, 1.00f, "64x256,tap9,2d,x2", 4},       // 13: ... and Cout <= 64
     {128, 128, 3, 1.00f, "128x128,K32,S3,x3", 4},      // 14: conv_dma again: 48 KiB LDS, <= 80 VGPRs: three workgroups per CU (short-K 1x1 layers)
+    {256, 224, 1, 1.00f, "256x224,tap9", 4},           // 15: conv_tap.hip variant 6 (see there)
 };
-static const int kNumCfgs = 15;
+static const int kNumCfgs = 16;
 static const int kFirstTapCfg = 8, kLastTapCfg = 13;
-static inline bool is_tap_cfg(int cfg) { return cfg >= kFirstTapCfg && cfg <= kLastTapCfg; }
+static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || cfg == 15; }
+static inline int tap_variant(int cfg) { return cfg == 15 ? 6 : cfg - kFirstTapCfg; }     // conv_tap.hip variant of a tap cfg
 bool dma_cfg_is_tap(int cfg) { return is_tap_cfg(cfg); }
-bool dma_cfg_f32_ok(int cfg) { return is_tap_cfg(cfg) && conv_tap_f32_ok(cfg - kFirstTapCfg); }
+bool dma_cfg_f32_ok(int cfg) { return is_tap_cfg(cfg) && conv_tap_f32_ok(tap_variant(cfg)); }
 
 // Pick the block tile that minimises rounds x tile time on 256 CUs (tail quantisation matters:
 // e.g. 38x38x512 at batch 32 is 362 tiles of 256x256 = 2 rounds at 71 % but 722 of 256x128 = 3 at 94 %).
@@ -255,7 +257,7 @@ bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok, int ksize, int
     if (cfg < 0 || cfg >= kNumCfgs) return false;
     const DmaCfg &k = kCfgs[cfg];
     if (cin_chunks % k.bkc) return false;
-    if (is_tap_cfg(cfg) && (ksize != 3 || stride != 1 || !conv_tap_fits(cfg - kFirstTapCfg, W))) return false;
+    if (is_tap_cfg(cfg) && (ksize != 3 || stride != 1 || !conv_tap_fits(tap_variant(cfg), W))) return false;
     if (k.na == 64) return cout <= 64 && (!is_tap_cfg(cfg) || cout > 32);
     return k.na <= (cout + 127) / 128 * 128 && cout > 64;
 }
@@ -286,6 +288,7 @@ static const TileCost kCost[] = {
     {0.90f, 1.10f, 0.60f, 17.0f},       // 12: 128x256 tap reuse, 2-D tiles (152x152 64->128: 175 us, 76x76: 117, 38x38: 138)
     {1.00f, 1.00f, 0.60f, 5.8f},        // 13: 64x256 tap reuse, 2-D tiles (chosen by rule below)
     {1.10f, 1.50f, 0.70f, 8.0f},        // 14: 128x128 K32 S3, three per CU: 1x1 layers only (short K, memory / latency bound)
+    {1.05f, 1.05f, 1.05f, 18.0f},       // 15: 256x224 tap reuse (7/8 of the 256x256 tile's loop)
 };
 
 int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W, bool tap_only) {
@@ -314,7 +317,7 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
         // tap-reuse tiles walk the padded position grid: (H+1)(W+1) positions per image (square maps assumed here)
         long long Meff = M;
         if (is_tap_cfg(c)) {
-            if (conv_tap_is2d(c - kFirstTapCfg)) { const long long t = (W + 15) / 16; Meff = (long long)M * t * t * 256 / ((long long)W * W); }
+            if (conv_tap_is2d(tap_variant(c))) { const long long t = (W + 15) / 16; Meff = (long long)M * t * t * 256 / ((long long)W * W); }
             else Meff = (long long)M * (W + 1) * (W + 1) / ((long long)W * W);
         }
         const long long blocks = (Meff + k.nb - 1) / k.nb * ((cout + k.na - 1) / k.na);
@@ -339,6 +342,8 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
 
 int dma_num_cfgs() { return kNumCfgs; }
 int dma_cfg_na(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg].na : 128; }
+int dma_cfg_nb(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg].nb : 128; }
+bool dma_cfg_splitk_ok(int cfg) { return is_tap_cfg(cfg) && conv_tap_splitk_ok(tap_variant(cfg)); }
 int dma_cfg_bkc(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg].bkc : 8; }
 const char *dma_cfg_name(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg].name : ""; }
 
@@ -367,7 +372,7 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
     conv_set_divisors(p, p.cin_chunks / k.bkc);
     if (is_tap_cfg(cfg)) {          // padded-linear position grid: one shared pad column per row, one pad row per image
         long long mq;
-        if (conv_tap_is2d(cfg - kFirstTapCfg)) {     // 16 x 16 tiles: qW = tiles per tile row, qHW = tiles per image
+        if (conv_tap_is2d(tap_variant(cfg))) {     // 16 x 16 tiles: qW = tiles per tile row, qHW = tiles per image
             p.qW = (p.W + 15) / 16;
             p.qHW = p.qW * ((p.H + 15) / 16);
             mq = (long long)(p.M / p.HoWo) * p.qHW * 256;
@@ -389,7 +394,7 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
             const size_t bytes = (size_t)p.n_blocks * 64;
             if (hipMalloc((void **)&dev, bytes) != hipSuccess) return hipErrorOutOfMemory;
             p.trace = dev;
-            hipError_t e = launch_conv_tap(p, cfg - kFirstTapCfg, s);
+            hipError_t e = launch_conv_tap(p, tap_variant(cfg), s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);
             std::vector<unsigned long long> host((size_t)p.n_blocks * 8);
             if (e == hipSuccess) e = hipMemcpy(host.data(), dev, bytes, hipMemcpyDeviceToHost);
@@ -407,7 +412,7 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
             return e;
         }
 #endif
-        return launch_conv_tap(p, cfg - kFirstTapCfg, s);
+        return launch_conv_tap(p, tap_variant(cfg), s);
     }
     const dim3 grid((unsigned)blocks), block(512);
     switch (cfg) {
@@ -421,7 +426,7 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
 
 // the name rocprofv3's kernel trace prints for the kernel a tile id runs (yolo_kernel_info.symbol)
 const char *dma_cfg_symbol(int cfg, bool f32) {
-    if (is_tap_cfg(cfg)) return conv_tap_symbol(cfg - kFirstTapCfg, f32);
+    if (is_tap_cfg(cfg)) return conv_tap_symbol(tap_variant(cfg), f32);
     switch (cfg) {
 #define X(id, ...) case id: return "void yolo::conv_igemm_dma_kernel<" #__VA_ARGS__ ">(yolo::ConvParams)";
         YOLO_DMA_VARIANTS(X)

@@ -152,7 +152,9 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         b_off[j] = ok ? (uint32_t)(e * (long long)sizeof(T)) + csw_p : YOLO_INVALID_OFF;
     }
 
-    const int C = p.cin_chunks >> 2;        // 32-channel slices
+    // channel slices of this workgroup: all of them, or one K split's share (split-K, blockIdx.y)
+    const int c_begin = p.ksplit > 1 ? (int)blockIdx.y * p.kunits : 0;
+    const int C = p.ksplit > 1 ? ((c_begin + p.kunits < (p.cin_chunks >> 2)) ? c_begin + p.kunits : (p.cin_chunks >> 2)) : (p.cin_chunks >> 2);
     const int KT = 9 * C;
     auto issue_patch = [&](int c, int buf) {
         const uint32_t koff = (uint32_t)c * ROWB;
@@ -203,9 +205,9 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
 #ifdef YOLO_EXPERIMENT
     const unsigned long long t_setup = p.trace ? wall_clock64() : 0ull;
 #endif
-    issue_patch(0, 0);
-    issue_weights(0, 0, 0);
-    issue_weights(1, 0, 1);
+    issue_patch(c_begin, 0);
+    issue_weights(0, c_begin, 0);
+    issue_weights(1, c_begin, 1);
 
     // one 32-channel slice; the patch buffer index is a compile-time constant (LDS immediates, no address registers)
     auto run_slice = [&](int c, auto bufc) {
@@ -243,7 +245,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
             compute(tap % S, buf, MODE == 2 ? kh * PW + kw : kh * p.qW + kw);
         }
     };
-    for (int c = 0; c < C; c += 2) {
+    for (int c = c_begin; c < C; c += 2) {
         run_slice(c, std::integral_constant<int, 0>());
         if (c + 1 < C) run_slice(c + 1, std::integral_constant<int, 1>());
         if constexpr (F32) flush_acc<TM, TP>(acc, acc2);        // two 16-channel slices x 9 taps = 288 k per chain
@@ -258,6 +260,10 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
 #ifdef YOLO_EXPERIMENT
     const unsigned long long t_loop = p.trace ? wall_clock64() : 0ull;
 #endif
+    if (p.ksplit > 1) {
+        conv_store_partial<TM, TP, MODE>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr, (int)blockIdx.y);
+        return;
+    }
     conv_epilogue<T, TM, TP, MODE>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
 #ifdef YOLO_EXPERIMENT
     if (p.trace && tid == 0) {          // YOLO_CONV_TRACE: phase timestamps (100 MHz) + placement of wave 0 of every block
@@ -272,16 +278,20 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
 #endif
 }
 
+// (6 = 256 couts x 224 positions, one workgroup per CU: 19 x 19 maps at batch 32 are 12 800 padded positions -> 58 x 4 = 232
+// tiles on 256 CUs, where the 256-position tiles leave 200 or 400 workgroups on 256 / 512 slots)
 // variants: 0 = 128 couts x 256 positions, 1 = 256 x 256 (one workgroup per CU), 2 = 128 x 192, 3 = 128 x 128 (smaller
 // position tiles fill the 512 workgroup slots of the chip better on small feature maps), all padded-linear;
 // 4 = 128 x (16 x 16) and 5 = 64 x (16 x 16) 2-D tiles for maps wider than 78 (any width)
-static const int kTapNB[] = {256, 256, 192, 128, 256, 256};
-static const int kTapPRG[] = {26, 26, 26, 28, 27, 27};
-static const bool kTapF32[] = {false, false, false, true, false, true};      // float32 tiles: TP <= 2 (second-level accumulator)
-bool conv_tap_is2d(int variant) { return variant >= 4; }
-bool conv_tap_f32_ok(int variant) { return variant >= 0 && variant <= 5 && kTapF32[variant]; }
+static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224};
+static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17};
+static const int kTapVariants = 7;
+static const bool kTapF32[] = {false, false, false, true, false, true, false};      // float32 tiles: TP <= 2 (second-level accumulator)
+bool conv_tap_splitk_ok(int variant) { return variant >= 0 && variant < kTapVariants && !(variant == 4 || variant == 5); }    // padded-linear tiles
+bool conv_tap_is2d(int variant) { return variant == 4 || variant == 5; }
+bool conv_tap_f32_ok(int variant) { return variant >= 0 && variant < kTapVariants && kTapF32[variant]; }
 bool conv_tap_fits(int variant, int W) {
-    if (variant < 0 || variant > 5) return false;
+    if (variant < 0 || variant >= kTapVariants) return false;
     if (conv_tap_is2d(variant)) return true;
     return kTapNB[variant] + 2 * W + 4 <= kTapPRG[variant] * 16;
 }
@@ -294,7 +304,8 @@ bool conv_tap_fits(int variant, int W) {
     X(2, 2, 4, 4, 3, 26, 4, 1) \
     X(3, 2, 4, 4, 2, 28, 4, 1) \
     X(4, 2, 4, 4, 4, 27, 4, 2) \
-    X(5, 1, 8, 4, 2, 27, 4, 2)
+    X(5, 1, 8, 4, 2, 27, 4, 2) \
+    X(6, 4, 2, 4, 7, 17, 2, 1)
 
 const char *conv_tap_symbol(int variant, bool f32) {
     switch (variant) {
@@ -310,7 +321,8 @@ hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
     if (p.ksize != 3 || p.stride != 1 || p.pad != 1 || p.Ho != p.H || p.Wo != p.W || (p.cin_chunks & 3) || !conv_tap_fits(variant, p.W) ||
         (p.f32 && !conv_tap_f32_ok(variant)))
         return hipErrorInvalidValue;
-    const dim3 grid((unsigned)p.n_blocks);
+    const dim3 grid((unsigned)p.n_blocks, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
+    if (p.ksplit > 1 && (!p.part || p.kunits < 1 || (long long)p.ksplit * p.kunits < (p.cin_chunks >> 2))) return hipErrorInvalidValue;
     switch (variant) {
 #define X(id, ...) case id: \
         if (p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<true, __VA_ARGS__>), grid, dim3(512), 0, s, p); \

@@ -87,6 +87,11 @@ struct ConvParams {
     int leaky, has_res, outmode, out_f32, vec_out, vec_res;
     int f32;                   // elements of input / weights / residual are float32 (else fp16)
     int n_tiles_n, n_blocks;
+    // split-K (small feature maps at small batch: a handful of tiles, each with a K of thousands): blockIdx.y = split s runs
+    // K units [s * kunits, (s + 1) * kunits) (conv_tap.hip: channel slices; conv.hip: K tiles) and stores its raw float32
+    // accumulators to part[s][pixel][cout_pad]; splitk_reduce_kernel (aux.hip) sums them and runs the fused epilogue
+    int ksplit, kunits, cout_pad;
+    float *part;
     int dbg;                   // experiment flags (YOLO_CONV_DBG): 1 skip steady-state DMA, 2 skip MFMA phase
     int qW, qHW, Mq;           // conv_tap.hip: padded-linear pixel grid, row stride W+1, image stride (H+1)(W+1), total
     float *obj_out;            // head convs (staged float32 epilogue): compact objectness logits [B][obj_rows] or null
@@ -166,6 +171,18 @@ struct EltParams {             // generic fallback: out[map(p)] = a[p] (+ b[p]);
     long long total;           // B*H*W*C
 };
 
+struct ReduceParams {          // aux.hip: splitk_reduce_kernel -- sum of the K splits + the conv epilogue (conv_common.h semantics)
+    const float *part;         // [ksplit][M][cout_pad]
+    const float *bias;
+    const void *res;           // residual (element pointer incl. coff) or null
+    void *out;
+    float *obj_out;            // head convs: compact objectness logits (see ConvParams)
+    int obj_width, obj_rows, obj_row0, obj_na;
+    int ksplit, M, Cout, cout_pad, HoWo, Wo;
+    int out_ld, res_ld, leaky, outmode, out_f32, f32;
+    long long out_img_stride, res_img_stride;
+};
+
 struct DecodeScale {
     int row0, h, w, na;
     double aw[YOLO_MAX_ANCHORS], ah[YOLO_MAX_ANCHORS];
@@ -228,6 +245,10 @@ std::string first_symbol(int dtype, int cout, bool pool);
 std::string aux_symbol(int kind, int dtype, bool vec);
 int dma_num_cfgs();
 int dma_cfg_na(int cfg);
+int dma_cfg_nb(int cfg);
+bool dma_cfg_splitk_ok(int cfg);        // the kernel behind this tile id takes ConvParams.ksplit
+hipError_t launch_splitk_reduce(const ReduceParams &p, hipStream_t s);
+bool conv_tap_splitk_ok(int variant);
 hipError_t launch_prep(const PrepParams &p, int dtype, hipStream_t s);
 hipError_t launch_resize(const ResizeParams &p, hipStream_t s);
 hipError_t launch_first(const FirstParams &p, int dtype, hipStream_t s);
@@ -282,6 +303,7 @@ struct yolo_net {
     size_t weights_bytes = 0;
     size_t act_bytes = 0;          // activation part of the workspace
     size_t logits_off = 0, cand_off = 0, count_off = 0, nms_off = 0;   // nms_off: global NMS slabs (cand_capacity > 4096)
+    size_t splitk_off = 0, splitk_bytes = 0;   // float32 partial-sum slabs of the split-K convs (small feature maps at small batch)
     size_t obj_off = 0, obj_bytes = 0;     // compact objectness logits [max_batch][rows] written by the head convs for the decode
     bool obj_valid = false;                // ... and whether the last forward filled all of it
     std::vector<hipStream_t> side;         // multi-stream forward (YOLO_STREAMS=N): internal streams + fork/join events

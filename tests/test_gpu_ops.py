@@ -242,7 +242,7 @@ def test_fused_stem(shape):
     assert ("conv_stem<f16,3-32-64>" in names2) == (H % 2 == 0 and W % 2 == 0) and "3-32-64-32" not in names2, names2
 
 
-@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15])
 def test_tap_reuse_tile_configs(tile):
     """tap-reuse tiles of conv_tap.hip (3x3/1 only: patch of 1, 2, 4 and 6 channel slices, image borders inside a
     block, position tail; the other layers fall back to the default choice) forced through yolo_net_options.force_tile: K-stage counts 1, 2 (shorter than the
@@ -272,7 +272,7 @@ def test_tap_reuse_tile_configs(tile):
 
 @pytest.mark.parametrize("shape", [(2, 19, 19, 512, 256), (3, 38, 38, 64, 128), (1, 76, 76, 128, 256), (2, 7, 78, 32, 128),
                                    (2, 5, 110, 64, 128), (1, 9, 152, 64, 128), (2, 33, 100, 32, 64), (1, 48, 304, 32, 64)])
-@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15])
 def test_tap_reuse_conv_shapes(shape, tile):
     """conv_tap.hip on the feature-map sizes of YOLOv3-608 (19, 38, 76), the widest rows its padded-linear tiles take
     (78, 110, 158 >= 152), wide maps for the 2-D tiles (partial 16x16 tiles in both directions, Cout 64) and a residual
@@ -291,8 +291,8 @@ def test_tap_reuse_conv_shapes(shape, tile):
         if dict(((11, cout > 64 and W <= 158), (13, cout == 64)))[tile]:
             assert "tap9" in " ".join(ki.name.decode() for ki in eng32.kernel_infos())
     names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
-    max_w = {8: 78, 9: 78, 10: 110, 11: 158, 12: 1 << 20, 13: 1 << 20}[tile]
-    need = {8: cout > 64, 9: cout >= 256, 10: cout > 64, 11: cout > 64, 12: cout > 64, 13: cout == 64}[tile]
+    max_w = {8: 78, 9: 78, 10: 110, 11: 158, 12: 1 << 20, 13: 1 << 20, 15: 22}[tile]
+    need = {8: cout > 64, 9: cout >= 256, 10: cout > 64, 11: cout > 64, 12: cout > 64, 13: cout == 64, 15: cout >= 256}[tile]
     if W <= max_w and need:             # else: the forced tile is not valid for this layer, the default one runs
         assert "tap9" in names, names
 
@@ -318,3 +318,26 @@ def test_every_dma_tile_config(tile):
     eng = check_graph(g, x, "fp16", seed=3, read=(2, 5, 7, 10), tile=tile)
     names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
     assert "conv_igemm_dma" in names
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+@pytest.mark.parametrize("batch", [1, 2])
+def test_split_k_small_maps(dtype, batch):
+    """13 x 13 / 7 x 9 maps at batch 1-2: a launch is a handful of tiles with K in the thousands, so the K range is split over
+    workgroups (conv_tap.hip channel slices, conv.hip K tiles) and splitk_reduce_kernel sums the float32 partials and runs
+    the epilogue: bias + leaky, fused residual, reorg and upsample output maps, Cout tails (255, 320), float32 final layer"""
+    g = new_graph(13, 13, 64)
+    g.append(PL.conv2d_bn_act(g[-1].out, 512, 3, 1))                 # 1  3x3 Cin 64
+    g.append(PL.conv2d_bn_act(g[-1].out, 1024, 3, 1))                # 2  3x3 Cin 512: K = 4608
+    g.append(PL.conv2d_bn_act(g[-1].out, 512, 1, 1))                 # 3  1x1 Cin 1024
+    g.append(PL.conv2d_bn_act(g[-1].out, 1024, 3, 1))                # 4  3x3 + residual
+    g.append(PL.shortcut(g[-1].out, g[-3].out))                      # 5
+    g.append(PL.conv2d_bn_act(g[-1].out, 320, 3, 2))                 # 6  3x3/2 (4-wave kernel), Cout tail, 7x7
+    g.append(PL.conv2d_bn_act(g[-1].out, 256, 1, 1))                 # 7
+    g.append(PL.upsample(g[-1].out, 2))                              # 8  fused upsample -> 14x14
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 1, 1))                  # 9
+    g.append(PL.reorg(g[-1].out, 2))                                 # 10 fused reorg -> 7x7x256
+    g.append(PL.conv2d_bn_act(g[-1].out, 1024, 3, 1))                # 11
+    g.append(PL.conv2d_bn_act(g[-1].out, 255, 1, 1, use_batch_normalization=False, activation_fn="linear"))   # 12 float32 out
+    x = synth.synthetic_input(batch, 13, 13, 64, seed=31)
+    check_graph(g, x, dtype, seed=9, read=(2, 5, 6, 8, 10, 11))
