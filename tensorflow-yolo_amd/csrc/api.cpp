@@ -236,14 +236,15 @@ bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile) {
 // splitk_reduce_kernel.  Returns 1 when the launch stays whole.
 int choose_ksplit(const yolo_net *net, const Kernel &k, const ConvParams &p, int tile, int &ku) {
     ku = 0;
-    if (!net->splitk_bytes || p.M <= 0) return 1;
+    const size_t slab_bytes = net->splitk_bytes / (size_t)net->arenas;      // concurrent parts (streams) must not share a slab
+    if (!slab_bytes || p.M <= 0) return 1;
     long long blocks;
     int units, min_units;
     if (tile == 0) {
         const int na = k.cfg == CFG_N128 ? 128 : k.cfg == CFG_N64 ? 64 : 32, nb = k.cfg == CFG_N128 ? 128 : 256;
         blocks = ((long long)p.M + nb - 1) / nb * ((p.Cout + na - 1) / na);
         units = p.ktiles;
-        min_units = 8;                  // >= 256 (float32) / 512 (fp16) k per split
+        min_units = 2;                  // >= 64 (float32) / 128 (fp16) k per split: these launches are latency-bound, not MFMA-bound
     } else if (dma_cfg_is_tap(tile) && dma_cfg_splitk_ok(tile)) {
         const long long mq = (long long)(p.M / p.HoWo) * (p.H + 1) * (p.W + 1);        // padded-linear positions
         blocks = (mq + dma_cfg_nb(tile) - 1) / dma_cfg_nb(tile) * ((p.Cout + dma_cfg_na(tile) - 1) / dma_cfg_na(tile));
@@ -252,19 +253,22 @@ int choose_ksplit(const yolo_net *net, const Kernel &k, const ConvParams &p, int
     } else {
         return 1;
     }
-    if (blocks > 128 || units < 2 * min_units) return 1;
-    long long ks = 384 / blocks;
-    if (ks > units / min_units) ks = units / min_units;
-    if (ks > 32) ks = 32;
+    if (blocks > 256 || units < 2 * min_units) return 1;
+    // workgroups = blocks x ks: 512 (two per CU) when K is long enough for that many splits, else 256, else whatever K allows --
+    // a count between the two leaves some CUs with two workgroups and the rest with one, and the pairs set the time
+    const long long kmax = units / min_units < 32 ? units / min_units : 32;
+    long long ks = 512 / blocks;
+    if (ks > kmax) ks = 256 / blocks;
+    if (ks > kmax) ks = kmax;
     const size_t cout_pad = ((size_t)p.Cout + 127) / 128 * 128;
-    while (ks >= 2 && (size_t)ks * (size_t)p.M * cout_pad * 4 > net->splitk_bytes) --ks;
+    while (ks >= 2 && (size_t)ks * (size_t)p.M * cout_pad * 4 > slab_bytes) --ks;
     if (ks < 2) return 1;
     ku = (int)((units + ks - 1) / ks);
     return (units + ku - 1) / ku;       // every split owns at least one unit
 }
 
 // tile < 0: heuristic (choose_dma_cfg); 0: 4-wave kernel of conv.hip; > 0: conv_dma.hip tile id
-hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParams &p0, int tile, hipStream_t s) {
+hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParams &p0, int tile, hipStream_t s, int arena = 0) {
     if (!dma_eligible(net, k) || (tile > 0 && !conv_tile_valid(net, k, tile))) tile = 0;
     else if (tile < 0) tile = choose_dma_cfg(p0.M, k.cout, k.cpt, p0.taps, k.has_res, true, k.stride, k.in.W, net->opt.dtype == YOLO_DTYPE_F32);
     ConvParams p = p0;
@@ -273,7 +277,7 @@ hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParam
     if (ks > 1) {
         p.ksplit = ks; p.kunits = ku;
         p.cout_pad = (p.Cout + 127) / 128 * 128;
-        p.part = reinterpret_cast<float *>(net->dev_ws + net->splitk_off);
+        p.part = reinterpret_cast<float *>(net->dev_ws + net->splitk_off + (size_t)arena * (net->splitk_bytes / (size_t)net->arenas / 256 * 256));
     }
     hipError_t e = tile > 0 ? launch_conv_dma(p, tile, s) : launch_conv(p, net->opt.dtype, k.cfg, k.perchunk != 0, s);
     if (e != hipSuccess || ks <= 1) return e;
@@ -339,7 +343,7 @@ int run_forward_pass(yolo_net *net, const float *in_dev, int batch, float *out_d
             int rc = make_conv_params(net, k, P, batch, p);
             if (rc) return rc;
             if (k.head && p.obj_out) obj_rows_written += (long long)p.Ho * p.Wo * p.obj_na;
-            e = launch_conv_any(net, k, p, k.tile, s);
+            e = launch_conv_any(net, k, p, k.tile, s, P.arena);
             break;
         }
         case K_FIRST: {
