@@ -253,7 +253,7 @@ int choose_ksplit(const yolo_net *net, const Kernel &k, const ConvParams &p, int
     } else {
         return 1;
     }
-    if (blocks > 256 || units < 2 * min_units) return 1;
+    if (blocks > 128 || units < 2 * min_units) return 1;
     // workgroups = blocks x ks: 512 (two per CU) when K is long enough for that many splits, else 256, else whatever K allows --
     // a count between the two leaves some CUs with two workgroups and the rest with one, and the pairs set the time
     const long long kmax = units / min_units < 32 ? units / min_units : 32;
@@ -261,7 +261,11 @@ int choose_ksplit(const yolo_net *net, const Kernel &k, const ConvParams &p, int
     if (ks > kmax) ks = 256 / blocks;
     if (ks > kmax) ks = kmax;
     const size_t cout_pad = ((size_t)p.Cout + 127) / 128 * 128;
-    while (ks >= 2 && (size_t)ks * (size_t)p.M * cout_pad * 4 > slab_bytes) --ks;
+    // the partial sums are written and read back once: worth it while that traffic stays in the order of the weight stream the
+    // launch reads anyway (measured: YOLOv2 13x13 at batch 1, 22 MB of partials beside 38 MB of weights, 553 -> 70 us; YOLOv3 19x19
+    // at batch 8, 47 MB beside 9 MB, slower than unsplit)
+    const size_t wbytes = (size_t)p.Cout * (size_t)p.taps * (size_t)p.cin_chunks * 16;
+    while (ks >= 2 && ((size_t)ks * (size_t)p.M * cout_pad * 4 > slab_bytes || (size_t)ks * (size_t)p.M * cout_pad * 4 > 2 * wbytes)) --ks;
     if (ks < 2) return 1;
     ku = (int)((units + ks - 1) / ks);
     return (units + ku - 1) / ku;       // every split owns at least one unit
