@@ -263,9 +263,9 @@ int choose_ksplit(const yolo_net *net, const Kernel &k, const ConvParams &p, int
     const size_t cout_pad = ((size_t)p.Cout + 127) / 128 * 128;
     // the partial sums are written and read back once: worth it while that traffic stays in the order of the weight stream the
     // launch reads anyway (measured: YOLOv2 13x13 at batch 1, 22 MB of partials beside 38 MB of weights, 553 -> 70 us; YOLOv3 19x19
-    // at batch 8, 47 MB beside 9 MB, slower than unsplit)
+    // at batch 8, 47 MB beside 9 MB, slower than unsplit); a few MB are always fine (L2-resident, ~2 us)
     const size_t wbytes = (size_t)p.Cout * (size_t)p.taps * (size_t)p.cin_chunks * 16;
-    while (ks >= 2 && ((size_t)ks * (size_t)p.M * cout_pad * 4 > slab_bytes || (size_t)ks * (size_t)p.M * cout_pad * 4 > 2 * wbytes)) --ks;
+    while (ks >= 2 && ((size_t)ks * (size_t)p.M * cout_pad * 4 > slab_bytes || (size_t)ks * (size_t)p.M * cout_pad * 4 > (2 * wbytes > ((size_t)8 << 20) ? 2 * wbytes : ((size_t)8 << 20)))) --ks;
     if (ks < 2) return 1;
     ku = (int)((units + ks - 1) / ks);
     return (units + ku - 1) / ku;       // every split owns at least one unit
