@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 from .. import _hip
-from . import base, dist as ydist, engine, v2, v3
+from . import base, dist as ydist, engine, tfckpt, v2, v3
 
 
 class Yolo(object):
@@ -120,12 +120,19 @@ class Yolo(object):
         # images shards over the ranks, the box records are all-gathered, rank 0 draws and writes (net/dist.py)
         rank, world = ydist.world()
         self.build(anchors, class_names, input_shape, dtype=dtype, max_batch=-(-batch_size // world))
-        # TF checkpoints cannot be read without TensorFlow; same fallback order as the reference,
-        # whose restore failure falls through to the Darknet weights (net/base.py:55-61, net/yolo.py:72-78)
+        # same order as the reference (net/yolo.py:71-78, net/base.py:55-61): restore the TensorFlow checkpoint (read without
+        # TensorFlow by net/tfckpt.py); when that fails, say so and load the Darknet weights
+        restored = False
         if checkpoint_path:
-            print("Failed to load {}: TensorFlow checkpoints are not supported by the HIP backend".format(checkpoint_path))
-        type(self).load_weights(self.net, pretrained_weights_path)
-        print("Pre-trained weights loaded.")
+            try:
+                v3.attach_weights(self.net, tfckpt.checkpoint_to_darknet(self.net, checkpoint_path))
+                restored = True
+                print("Checkpoint {} restored.".format(checkpoint_path))
+            except Exception as e:
+                print("Failed to load {}: {}".format(checkpoint_path, str(e)))
+        if not restored:
+            type(self).load_weights(self.net, pretrained_weights_path)
+            print("Pre-trained weights loaded.")
 
         # resize / colour order / /255 run on the device with OpenCV's INTER_LINEAR arithmetic (base.preprocess_image_gpu);
         # `preprocess = pillow` (new optional key) keeps the host-side Pillow resampler

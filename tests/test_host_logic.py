@@ -119,3 +119,45 @@ def test_image_preprocess_and_draw(tmp_path):
     out = base.draw_boxes(p, [BoundingBox(x=0.5, y=0.5, w=0.5, h=0.5, class_idx=7, prob=0.8)], ["n%d" % i for i in range(8)])
     base.save_image(out, str(tmp_path / "o" / "img_out.png"))
     assert os.path.exists(str(tmp_path / "o" / "img_out.png"))
+
+
+def test_tf_checkpoint_bundle_roundtrip_and_darknet_order(tmp_path):
+    """net/tfckpt.py: a checkpoint with the reference's variable names (net/layers.py:53-63; kernels HWIO)
+    -> the Darknet stream; PARITY UNPINNED against TensorFlow itself (absent): format restated, round trip only"""
+    from tensorflow_yolo_amd.net import tfckpt
+    names = ["c%d" % i for i in range(20)]
+    net = v2.create_tiny_network(np.reshape(cases.VOC_TINY_ANCHORS, [-1, 2]), names, False, input_shape=(96, 96, 3))
+    w = synth.darknet_stream(net, seed=3, num_classes=20)
+    prefix = str(tmp_path / "yolo-20")
+    tfckpt.darknet_to_checkpoint(net, w, prefix)
+    assert os.path.exists(prefix + ".index") and os.path.exists(prefix + ".data-00000-of-00001")
+    b = tfckpt.Bundle(prefix)
+    assert "yolo/conv2d_bn_act_0/kernel" in b.entries and "yolo/conv2d_bn_act_8/bias" in b.entries and b.num_shards == 1
+    k0 = b.read("yolo/conv2d_bn_act_0/kernel")
+    assert k0.shape == (3, 3, 3, 16) and k0.dtype == np.float32                     # HWIO, as tf.layers.conv2d keeps it
+    # darknet order: beta, gamma, mean, var, then kernel [out][in][kh][kw] (net/base.py:36-40 transposes it to HWIO)
+    assert np.array_equal(np.transpose(k0, (3, 2, 0, 1)).ravel(), w[64:64 + 16 * 27])
+    assert np.array_equal(b.read("yolo/conv2d_bn_act_0/gamma"), w[16:32])
+    back = tfckpt.checkpoint_to_darknet(net, prefix)
+    assert back.dtype == np.float32 and np.array_equal(back, w)
+    # a checkpoint of another graph fails like the reference's restore does
+    other = v2.create_tiny_network(np.reshape(cases.VOC_TINY_ANCHORS, [-1, 2]), names[:5], False, input_shape=(96, 96, 3))
+    with pytest.raises(ValueError, match="shape"):
+        tfckpt.checkpoint_to_darknet(other, prefix)
+    with pytest.raises(IOError):
+        tfckpt.Bundle(str(tmp_path / "missing"))
+    # corrupt index block -> checksum error
+    raw = bytearray(open(prefix + ".index", "rb").read())
+    raw[10] ^= 0xff
+    open(prefix + ".index", "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="checksum"):
+        tfckpt.Bundle(prefix)
+
+
+def test_tfckpt_primitives():
+    from tensorflow_yolo_amd.net import tfckpt
+    assert tfckpt.crc32c(b"123456789") == 0xe3069283                                # the CRC-32C check value
+    assert tfckpt._snappy_decompress(b"\x0b\x14hello \x05\x06") == b"hello hello"   # literal + 1-byte-offset copy
+    assert tfckpt._snappy_decompress(b"\x03\x08abc") == b"abc"
+    for n in (0, 1, 127, 128, 300, 2 ** 40):
+        assert tfckpt._varint(tfckpt._put_varint(n), 0) == (n, len(tfckpt._put_varint(n)))
