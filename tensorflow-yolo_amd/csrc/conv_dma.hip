@@ -303,6 +303,11 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
         if (M >= 8192 && dma_cfg_valid(13, cout, cin_chunks, v1_ok, ksize, stride, W)) return 13;
         return !tap_only && dma_cfg_valid(7, cout, cin_chunks, v1_ok, ksize, stride, W) && M >= 8192 ? 7 : fallback;
     }
+    // wide maps with a short K (152x152 64 -> 128 at batch 32: 172 us on the 128 x 128 tap tile, 181 on the per-tap LDS-DMA tile
+    // the model picks, r02 sweep): the tap-reuse tile with the smallest patch wins where the launch is bandwidth-bound
+    if (!tap_only && taps == 9 && stride == 1 && W > 110 && cout <= 128 && cin_chunks <= 8 && M >= 262144 &&
+        dma_cfg_valid(11, cout, cin_chunks, v1_ok, ksize, stride, W))
+        return 11;
     const double k64 = taps * cin_chunks / 8.0;         // 64-deep K tiles
     int best = fallback;
     double best_t = 1e300;

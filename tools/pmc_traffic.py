@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """rocprofv3 --pmc passes (tools/gpu_pmc.sh) -> profiles/traffic.json: HBM bytes per launch of every kernel
-family bench.py names (FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM': on gfx950 it reports half the bytes of a
+symbol (the key bench.py looks up: roofline.kernel_symbol) (FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM': on gfx950 it reports half the bytes of a
 wide coalesced stream; WRITE_SIZE as is; both in KiB)."""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
@@ -8,33 +8,11 @@ from collections import defaultdict
 root = sys.argv[1]
 workload = sys.argv[2] if len(sys.argv) > 2 else "v3-608-b32-fp16"
 out_path = sys.argv[3] if len(sys.argv) > 3 else "profiles/traffic.json"
-DMA = {(2, 4, 8, 4, 2, 8, 2): "256x256,K64,S2", (4, 2, 4, 4, 3, 8, 2): "256x128,K64,S3", (2, 4, 4, 4, 3, 8, 2): "128x256,K64,S3",
-       (2, 4, 8, 4, 4, 4, 2): "256x256,K32,S4", (4, 2, 4, 4, 3, 4, 4): "256x128,K32,S3,x2", (2, 4, 4, 4, 3, 4, 4): "128x256,K32,S3,x2",
-       (1, 8, 4, 4, 2, 4, 4): "64x512,K32,S2,x2"}
 
 
 def family(name):
-    m = re.search(r"conv_igemm_dma_kernel<([\d, ]+)>", name)
-    if m:
-        return "conv_igemm_dma<f16,%s>" % DMA.get(tuple(int(v) for v in m.group(1).split(",")), m.group(1))
-    m = re.search(r"conv3x3_tap_kernel<(?:_Float16|float), ([\d, ]+)>", name) or re.search(r"conv3x3_tap_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
-    if m:
-        v = tuple(int(x) for x in (m.group(1).split(",") if m.lastindex == 1 else m.groups()))
-        return "conv_igemm_dma<f16,%s>" % {(2, 4, 4, 4): "128x256,tap9,x2", (2, 4, 8, 4): "256x256,tap9", (2, 4, 4, 3): "128x192,tap9,x2",
-                                           (2, 4, 4, 2): "128x128,tap9,x2"}.get(v[:4], str(v)) if (len(v) < 7 or v[6] == 1) else \
-            "conv_igemm_dma<f16,%s>" % {(2, 4, 4, 4): "128x256,tap9,2d,x2", (1, 8, 4, 2): "64x256,tap9,2d,x2"}.get(v[:4], str(v))
-    if "stem_v3_kernel" in name:
-        return "conv_stem<f16,3-32-64>"
-    m = re.search(r"conv_first_kernelI(DF16_|f)Li(\d+)", name)
-    if m:
-        return "conv_first<%s,%s>" % ("f16" if m.group(1) == "DF16_" else "f32", m.group(2))
-    m = re.search(r"conv_igemm_kernelI(DF16_|f)Li(\d)ELi(\d)ELi(\d)ELi(\d)ELb([01])", name)
-    if m:
-        n = {(2, 2): 128, (1, 4): None}[(int(m.group(2)), int(m.group(3)))]
-        if n is None:
-            n = 64 if m.group(4) == "4" else 32
-        return "conv_igemm<%s,N%d,%s>" % ("f16" if m.group(1) == "DF16_" else "f32", n, "perchunk" if m.group(6) == "1" else "uniform")
-    return None
+    """key = the kernel's name as rocprofv3 prints it = yolo_kernel_info.symbol = bench.py's roofline.kernel_symbol"""
+    return name if "yolo::" in name else None
 
 
 acc = defaultdict(lambda: defaultdict(list))
