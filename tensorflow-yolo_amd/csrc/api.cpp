@@ -277,7 +277,14 @@ hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParam
     else if (tile < 0) tile = choose_dma_cfg(p0.M, k.cout, k.cpt, p0.taps, k.has_res, true, k.stride, k.in.W, net->opt.dtype == YOLO_DTYPE_F32);
     ConvParams p = p0;
     int ku = 0;
-    const int ks = choose_ksplit(net, k, p, tile, ku);
+    int ks = choose_ksplit(net, k, p, tile, ku);
+    // a 3x3/1 layer small enough for split-K runs it on the 128 x 128 tap tile (the one with the split-K instantiation), whatever
+    // tile the cost model would pick for the whole-K launch
+    if (ks <= 1 && tile > 0 && dma_cfg_is_tap(tile) && tile != 11 && conv_tile_valid(net, k, 11)) {
+        int ku11 = 0;
+        const int ks11 = choose_ksplit(net, k, p, 11, ku11);
+        if (ks11 > 1) { tile = 11; ks = ks11; ku = ku11; }
+    }
     if (ks > 1) {
         p.ksplit = ks; p.kunits = ku;
         p.cout_pad = (p.Cout + 127) / 128 * 128;

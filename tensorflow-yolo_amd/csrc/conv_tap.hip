@@ -61,7 +61,10 @@ __device__ __forceinline__ int tap_swz_w(int r) { return (0x78 >> (2 * ((r >> 2)
 // fragment pair: the exact fp32 FMA chain of conv.hip) -- the LDS geometry is in 16-byte chunks either way.
 // (F32 instead of the element type as template parameter: rocprofv3 does not demangle `_Float16` template arguments, and
 // yolo_kernel_info.symbol must be the name its kernel trace prints)
-template <bool F32, int WM, int WN, int TM, int TP, int PRG, int OCC, int MODE>
+// SPLITK: the split-K instantiation (blockIdx.y = K split, raw float32 partial sums out; 128 x 128 tile only).  A template
+// parameter, not a run-time branch: with the branch in the code the register allocation of the big tiles changed (46-64
+// VGPRs spilled, scratch traffic doubling the kernel's HBM writes: profiles/r02_ablation.md).
+template <bool F32, int WM, int WN, int TM, int TP, int PRG, int OCC, int MODE, bool SPLITK>
 __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams p) {
     typedef typename std::conditional<F32, float, _Float16>::type T;
     constexpr int NW = 8;
@@ -81,6 +84,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     static_assert(JA_TOT % NW == 0 || JA_TOT < NW, "weight tile must split evenly over the waves (or be smaller than them)");
     static_assert(MODE == 1 || PRG * 16 >= (NB / 16 + 2) * PW, "patch buffer too small for the 2-D tile");
     if constexpr (F32 && TP > 2) return;    // never launched (launch_conv_tap refuses): no registers for the second accumulator
+    if constexpr (SPLITK && !(WM == 2 && WN == 4 && TM == 4 && TP == 2 && MODE == 1)) return;      // split-K: the 128 x 128 tile only
     __shared__ __attribute__((aligned(16))) unsigned char smem[S * A_BYTES + 2 * P_BYTES];
     unsigned char *const smemP = smem + S * A_BYTES;
 
@@ -153,8 +157,8 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     }
 
     // channel slices of this workgroup: all of them, or one K split's share (split-K, blockIdx.y)
-    const int c_begin = p.ksplit > 1 ? (int)blockIdx.y * p.kunits : 0;
-    const int C = p.ksplit > 1 ? ((c_begin + p.kunits < (p.cin_chunks >> 2)) ? c_begin + p.kunits : (p.cin_chunks >> 2)) : (p.cin_chunks >> 2);
+    const int c_begin = SPLITK ? (int)blockIdx.y * p.kunits : 0;
+    const int C = SPLITK ? ((c_begin + p.kunits < (p.cin_chunks >> 2)) ? c_begin + p.kunits : (p.cin_chunks >> 2)) : (p.cin_chunks >> 2);
     const int KT = 9 * C;
     auto issue_patch = [&](int c, int buf) {
         const uint32_t koff = (uint32_t)c * ROWB;
@@ -260,11 +264,12 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
 #ifdef YOLO_EXPERIMENT
     const unsigned long long t_loop = p.trace ? wall_clock64() : 0ull;
 #endif
-    if (p.ksplit > 1) {
+    if constexpr (SPLITK) {
         conv_store_partial<TM, TP, MODE>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr, (int)blockIdx.y);
         return;
+    } else {
+        conv_epilogue<T, TM, TP, MODE>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
     }
-    conv_epilogue<T, TM, TP, MODE>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
 #ifdef YOLO_EXPERIMENT
     if (p.trace && tid == 0) {          // YOLO_CONV_TRACE: phase timestamps (100 MHz) + placement of wave 0 of every block
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -287,7 +292,7 @@ static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224};
 static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17};
 static const int kTapVariants = 7;
 static const bool kTapF32[] = {false, false, false, true, false, true, false};      // float32 tiles: TP <= 2 (second-level accumulator)
-bool conv_tap_splitk_ok(int variant) { return variant >= 0 && variant < kTapVariants && !(variant == 4 || variant == 5); }    // padded-linear tiles
+bool conv_tap_splitk_ok(int variant) { return variant == 3; }      // the 128 x 128 tile has the split-K instantiation
 bool conv_tap_is2d(int variant) { return variant == 4 || variant == 5; }
 bool conv_tap_f32_ok(int variant) { return variant >= 0 && variant < kTapVariants && kTapF32[variant]; }
 bool conv_tap_fits(int variant, int W) {
@@ -309,8 +314,8 @@ bool conv_tap_fits(int variant, int W) {
 
 const char *conv_tap_symbol(int variant, bool f32) {
     switch (variant) {
-#define X(id, ...) case id: return f32 ? "void yolo::conv3x3_tap_kernel<true, " #__VA_ARGS__ ">(yolo::ConvParams)" \
-                                       : "void yolo::conv3x3_tap_kernel<false, " #__VA_ARGS__ ">(yolo::ConvParams)";
+#define X(id, ...) case id: return f32 ? "void yolo::conv3x3_tap_kernel<true, " #__VA_ARGS__ ", false>(yolo::ConvParams)" \
+                                       : "void yolo::conv3x3_tap_kernel<false, " #__VA_ARGS__ ", false>(yolo::ConvParams)";
         YOLO_TAP_VARIANTS(X)
 #undef X
     default: return "";
@@ -322,11 +327,16 @@ hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
         (p.f32 && !conv_tap_f32_ok(variant)))
         return hipErrorInvalidValue;
     const dim3 grid((unsigned)p.n_blocks, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
-    if (p.ksplit > 1 && (!p.part || p.kunits < 1 || (long long)p.ksplit * p.kunits < (p.cin_chunks >> 2))) return hipErrorInvalidValue;
+    if (p.ksplit > 1) {     // split-K instantiation (128 x 128 tile)
+        if (!conv_tap_splitk_ok(variant) || !p.part || p.kunits < 1 || (long long)p.ksplit * p.kunits < (p.cin_chunks >> 2)) return hipErrorInvalidValue;
+        if (p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<true, 2, 4, 4, 2, 28, 4, 1, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv3x3_tap_kernel<false, 2, 4, 4, 2, 28, 4, 1, true>), grid, dim3(512), 0, s, p);
+        return hipGetLastError();
+    }
     switch (variant) {
 #define X(id, ...) case id: \
-        if (p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<true, __VA_ARGS__>), grid, dim3(512), 0, s, p); \
-        else hipLaunchKernelGGL((conv3x3_tap_kernel<false, __VA_ARGS__>), grid, dim3(512), 0, s, p); \
+        if (p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<true, __VA_ARGS__, false>), grid, dim3(512), 0, s, p); \
+        else hipLaunchKernelGGL((conv3x3_tap_kernel<false, __VA_ARGS__, false>), grid, dim3(512), 0, s, p); \
         break;
         YOLO_TAP_VARIANTS(X)
 #undef X

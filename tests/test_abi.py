@@ -161,3 +161,44 @@ def test_kernel_info_symbols_are_real_kernels_of_the_library():
                     assert sym in exported, (ki.name.decode(), sym)
                     seen.add(sym)
     assert len(seen) >= 10
+
+
+def test_dominant_kernel_register_allocation_is_guarded():
+    """The headline kernel sits at the 128-register limit of two workgroups per CU: an innocent-looking edit elsewhere in
+    conv_tap.hip (a run-time split-K branch, a tile loop) pushed 46-64 VGPRs to scratch twice in round 2 and doubled its HBM
+    writes before the PMC counters showed it.  hipcc's resource remarks for the fp16 instantiations the YOLOv3 step runs:
+    no spill in the K loop's big tiles beyond the 8 epilogue VGPRs of the 128 x 256 tile, occupancy as designed."""
+    import os
+    import re
+    import subprocess
+    src = os.path.join(ROOT, "tensorflow-yolo_amd", "csrc", "conv_tap.hip")
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                          "--cuda-device-only", "-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"],
+                         capture_output=True, text=True, cwd=os.path.dirname(src)).stderr
+    rows, cur = {}, None
+    for line in out.splitlines():
+        m = re.search(r"remark: +(.*?) \[-Rpass", line)
+        if not m:
+            continue
+        t = m.group(1).strip()
+        if t.startswith("Function Name:"):
+            cur = t.split(": ", 1)[1]
+            rows[cur] = {}
+        elif cur and ":" in t:
+            k, v = t.split(":", 1)
+            rows[cur][k.strip()] = v.strip()
+    want = {   # mangled template arguments: F32, WM, WN, TM, TP, PRG, OCC, MODE, SPLITK -> (max spilled VGPRs, waves / SIMD)
+        "ILb0ELi2ELi4ELi4ELi4ELi26ELi4ELi1ELb0EE": (8, 4),      # 128 x 256, two workgroups per CU: the roofline kernel
+        "ILb0ELi2ELi4ELi8ELi4ELi26ELi2ELi1ELb0EE": (0, 2),      # 256 x 256
+        "ILb0ELi4ELi2ELi4ELi7ELi17ELi2ELi1ELb0EE": (0, 2),      # 256 x 224
+        "ILb0ELi2ELi4ELi4ELi3ELi26ELi4ELi1ELb0EE": (0, 4),      # 128 x 192
+        "ILb0ELi2ELi4ELi4ELi2ELi28ELi4ELi1ELb0EE": (0, 4),      # 128 x 128
+        "ILb0ELi2ELi4ELi4ELi2ELi28ELi4ELi1ELb1EE": (0, 4),      # 128 x 128 split-K
+    }
+    seen = 0
+    for name, r in rows.items():
+        for key, (max_spill, occ) in want.items():
+            if "conv3x3_tap_kernel" + key in name:
+                seen += 1
+                assert int(r["VGPRs Spill"]) <= max_spill and int(r["Occupancy [waves/SIMD]"]) == occ, (name, r)
+    assert seen == len(want), sorted(rows)
