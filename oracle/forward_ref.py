@@ -1,7 +1,9 @@
 """Oracle (test infrastructure): CPU restatement of the reference's TF conv-stack forward.
 
-PARITY UNPINNED (see oracle/__init__.py): TensorFlow is absent and the reference
-holds no golden logits.  Every function cites the reference call site it follows.
+ARITHMETIC PARITY UNPINNED (see oracle/__init__.py): TensorFlow is absent and the reference
+holds no golden logits.  The TOPOLOGY and the Darknet weight order this module walks ARE pinned to the
+reference's own builders (tests/golden/topology_*.json, oracle/gen_topology.py).  Every function cites the
+reference call site it follows.
 
 All tensors are NHWC like the reference's graph (net/layers.py:108); torch-CPU is
 used for the convolution arithmetic only.
@@ -85,7 +87,7 @@ def _conv_folded_fp16(x, wd, k, s, bn, act, dtype, head):
     y = y + bias
     if act == "leaky":
         y = torch.maximum(_LEAKY * y, y)
-    return y if head else y
+    return y            # (`head`: the caller keeps head-conv outputs in float32, everything else is rounded to fp16 there)
 
 
 def _conv(x, wd, k, s, bn, act, dtype):
