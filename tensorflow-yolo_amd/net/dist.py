@@ -47,13 +47,14 @@ def world(group=None):
     return dist.get_rank(group), dist.get_world_size(group)
 
 
-def gather_records(flat, group=None):
+def gather_records(flat, group=None, always=False):
     """The path's only collective: all-gather of the per-rank record buffer.
-    flat: [record_words] int32 (device or CPU).  Returns [world, record_words]; rank order == image order."""
+    flat: [record_words] int32 (device or CPU).  Returns [world, record_words]; rank order == image order.
+    `always`: issue the collective even in a one-rank group (the GPU test uses it to put this exact call through RCCL)."""
     import torch
     import torch.distributed as dist
     _, w = world(group)
-    if w == 1:
+    if w == 1 and not (always and dist.is_available() and dist.is_initialized()):
         return flat.reshape(1, -1)
     out = torch.empty(w * flat.numel(), dtype=flat.dtype, device=flat.device)
     dist.all_gather_into_tensor(out, flat.contiguous().reshape(-1), group=group)
