@@ -145,4 +145,5 @@ def test_bench_self_launches_ranks_without_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode not in (0, 2), r.stderr[-2000:]
-    assert "rank 0 needs GPU 0" in r.stderr and "rank 1 needs GPU 1" in r.stderr, r.stderr[-2000:]
+    # (the launcher tears the other rank down as soon as one has failed, so only one of the two messages is guaranteed)
+    assert "rank 0 needs GPU 0" in r.stderr or "rank 1 needs GPU 1" in r.stderr, r.stderr[-2000:]
