@@ -282,7 +282,7 @@ def main():
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16" if dtype == "fp16" else "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "model": kind, "input": [size, size, 3], "batch_per_gpu": batch,
+            "config": {"workload": args.workload, "network": kind, "input": [size, size, 3], "batch_per_gpu": batch,
                        "global_batch": batch * world, "weights": "seeded synthetic Darknet stream (random-init)",
                        "threshold": args.threshold, "iou_threshold": args.iou_threshold, "streams": max(1, args.streams),
                        "sharding": "images over ranks; all-gather of box records only" if world > 1 else "single GPU",
