@@ -258,8 +258,9 @@ def records_to_host(boxes, counts, status, allow_truncation=False):
     cls = boxes[..., 5].view(np.int32)
     for i in range(boxes.shape[0]):
         n = int(counts[i])
-        out.append([(float(boxes[i, k, 0]), float(boxes[i, k, 1]), float(boxes[i, k, 2]), float(boxes[i, k, 3]),
-                     int(cls[i, k]), float(boxes[i, k, 4])) for k in range(n)])
+        b = boxes[i, :n].astype(np.float64).tolist()        # float32 -> the same Python floats as float(np.float32)
+        c = cls[i, :n].tolist()
+        out.append([(r[0], r[1], r[2], r[3], c[k], r[4]) for k, r in enumerate(b)])
     return out, status
 
 
