@@ -147,3 +147,17 @@ def find_bounding_boxes_v3(net_out, threshold, iou_threshold, scales, nms=True):
 def boxes_to_array(boxes):
     """[(x, y, w, h, class_idx, prob)] as float64 [N,6] (for fixtures / comparisons)."""
     return np.array([b.astuple() for b in boxes], dtype=np.float64).reshape(-1, 6)
+
+
+def non_maximum_suppression_per_class(boxes, iou_threshold):
+    """north_star's "per-class NMS" (opt-in; NOT what the reference does, net/base.py:195-209 never looks at class_idx):
+    the same stable sort and greedy pass, but only a kept box of the SAME class suppresses.  Output order = one list by
+    descending prob, like the reference's."""
+    if len(boxes) == 0:
+        return []
+    boxes = sorted(boxes, key=lambda b: b.prob, reverse=True)
+    kept = [boxes[0]]
+    for b in boxes[1:]:
+        if not any(int(k.class_idx) == int(b.class_idx) and iou_score(k, b) >= iou_threshold for k in kept):
+            kept.append(b)
+    return kept

@@ -5,7 +5,7 @@ Keeps the reference launcher's surface (reference launcher.py:15-60): the two fl
 COMMON / ANCHOR / TRAIN / TEST merged as {**section, **COMMON}, relative `*_dir` / `*_path` values
 resolved against the .ini's directory, `anchors` / `class_names` parsed as Python literals, and the
 network picked by COMMON.version.  Only `test` runs on this backend; `train` and `anchor` end with a
-clear message.  Extra, optional keys: `dtype` (fp32 | fp16), `nms_mode` (agnostic | per_class);
+clear message.  Extra, optional keys: `dtype` (fp32 | fp16), `nms_mode` (agnostic | per_class), `max_boxes` / `cand_capacity` (record caps);
 version additionally accepts `v2-tiny`.  `--section` selects another TEST-like section (the
 reference's yolo_2.ini keeps its COCO settings in [TEST_COCO], which no mode reaches there).
 """
@@ -67,7 +67,35 @@ def main(argv=None):
     ap.add_argument("--mode", dest="mode", help="Mode: (train|test|anchor)", default="anchor")
     ap.add_argument("--section", dest="section", help="section to use for test mode (default TEST)", default=None)
     args = ap.parse_args(argv)
-    run(read_config(args.config), args.mode.lower(), args.section)
+    group = init_distributed()
+    try:
+        run(read_config(args.config), args.mode.lower(), args.section)
+    finally:
+        if group:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+def init_distributed():
+    """One process per GPU: under a multi-process launcher (`torchrun launcher.py ...` sets WORLD_SIZE / RANK / LOCAL_RANK /
+    MASTER_*) bind this process to its GPU and join the group BEFORE anything touches the device, so that Yolo.test shards
+    every batch over the ranks (net/dist.py).  Backend "nccl" (= RCCL) on GPUs, "gloo" where there is none (the CPU tests).
+    Returns True when this call created the group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return False
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return False
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.device_count() > local_rank and torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return True
 
 
 if __name__ == "__main__":

@@ -163,21 +163,46 @@ def generate_test_batch(img_paths, batch_size, input_shape):
         yield np.stack(images, axis=0), chunk
 
 
+_LABEL_FONT = None
+
+
+def _label_font():
+    """A scalable default font whose cap height is close to cv2.FONT_HERSHEY_SIMPLEX at scale 0.5 (~11 px)."""
+    global _LABEL_FONT
+    if _LABEL_FONT is None:
+        from PIL import ImageFont
+        try:
+            _LABEL_FONT = ImageFont.load_default(12)
+        except TypeError:               # Pillow without the sized default font
+            _LABEL_FONT = ImageFont.load_default()
+    return _LABEL_FONT
+
+
 def draw_boxes(path_to_img, boxes, class_names):
-    """Rectangles (thickness 3) + "name prob" labels in the reference's colours, scaled to the
-    original image size, top-left clamped at 0 (reference net/base.py:212-226).  Returns a PIL image."""
+    """Rectangles + "name prob" labels as the reference draws them (net/base.py:212-226): corners scaled by the ORIGINAL image
+    size and clamped at 0 only, colour COLORS[class_idx % 6], `cv2.rectangle(..., thickness=3)` = a 3-pixel outline CENTRED on
+    the corner coordinates (one pixel either side), label with its BASELINE's left end at (tl.x, tl.y - 10) -- so a box at the
+    top edge loses its label, as there.  Pillow rasteriser (OpenCV is absent: glyph shapes differ, geometry does not).
+    Returns a PIL image."""
     from PIL import Image, ImageDraw
     image = Image.open(path_to_img).convert("RGB")
     w, h = image.size
     draw = ImageDraw.Draw(image)
+    font = _label_font()
     for box in boxes:
         tl = np.maximum(box.get_top_left(h, w), 0)
         br = np.maximum(box.get_bottom_right(h, w), 0)
         tl, br = (int(tl[0]), int(tl[1])), (int(br[0]), int(br[1]))
         bgr = COLORS[box.class_idx % len(COLORS)]
         rgb = (bgr[2], bgr[1], bgr[0])
-        draw.rectangle([tl, (max(br[0], tl[0]), max(br[1], tl[1]))], outline=rgb, width=3)
-        draw.text((tl[0], max(tl[1] - 12, 0)), "{} {:.3f}".format(class_names[box.class_idx], box.prob), fill=rgb)
+        x0, x1 = min(tl[0], br[0]), max(tl[0], br[0])
+        y0, y1 = min(tl[1], br[1]), max(tl[1], br[1])
+        draw.rectangle([(x0 - 1, y0 - 1), (x1 + 1, y1 + 1)], outline=rgb, width=3)
+        text = "{} {:.3f}".format(class_names[box.class_idx], box.prob)
+        try:
+            draw.text((tl[0], tl[1] - 10), text, fill=rgb, font=font, anchor="ls")
+        except (ValueError, TypeError):         # bitmap default font: no anchors; place its ~11-pixel box above the baseline
+            draw.text((tl[0], tl[1] - 21), text, fill=rgb, font=font)
     return image
 
 

@@ -15,8 +15,11 @@ so a restored checkpoint and a .weights file take the same path to the GPU.
 
 PARITY UNPINNED: TensorFlow is not installable here and the reference ships no checkpoint, so the format is restated from
 TensorFlow's published sources (tensor_bundle.proto, core/lib/io/format.cc, table_builder.cc) and checked by round trip
-against `write_bundle` below (same restatement) only.  Index blocks may be Snappy-compressed (decoder included); block and
-tensor CRCs are verified for the index, not for the tensor data (pure-Python CRC32C over hundreds of MB is impractical).
+against `write_bundle` below (same restatement) only.  Index blocks may be Snappy-compressed (decoder included); block CRCs of the index
+are always verified; the CRC of the tensor DATA is verified for tensors up to `VERIFY_DATA_CRC_BYTES` (bias / BN vectors, small
+kernels) and for every tensor with `Bundle(prefix, verify_data=True)` (pure-Python CRC32C over hundreds of MB is slow).
+tests/test_host_logic.py::test_tf_checkpoint_hand_assembled_index parses an index assembled byte by byte in the test from the
+published format (its own CRC and Snappy encoder), independent of `write_bundle`.
 """
 import os
 import struct
@@ -26,6 +29,7 @@ import numpy as np
 _MAGIC = 0xdb4775248b80fb57
 _DTYPES = {1: np.float32, 2: np.float64, 3: np.int32, 9: np.int64, 19: np.float16}     # tensorflow DataType enum
 _DTYPE_IDS = {np.dtype(v): k for k, v in _DTYPES.items()}
+VERIFY_DATA_CRC_BYTES = 64 << 10        # tensors up to this size always have their data CRC checked
 
 
 # ---- little helpers: varints, protobuf wire format, crc32c ------------------------------------------------------------------
@@ -214,8 +218,9 @@ def _parse_entry(buf):
 class Bundle(object):
     """Index of one checkpoint; tensors are read on demand."""
 
-    def __init__(self, prefix):
+    def __init__(self, prefix, verify_data=False):
         self.prefix = prefix
+        self.verify_data = bool(verify_data)
         index = prefix + ".index"
         if not os.path.exists(index):
             raise IOError("%s not found" % index)
@@ -248,6 +253,9 @@ class Bundle(object):
             arr = np.fromfile(f, dtype=dt.newbyteorder("<"), count=count)
         if arr.size != count:
             raise ValueError("%s: data shard %s is truncated" % (name, path))
+        if e["crc32c"] is not None and (self.verify_data or e["size"] <= VERIFY_DATA_CRC_BYTES):
+            if _mask(crc32c(arr.tobytes())) != e["crc32c"]:
+                raise ValueError("%s: tensor data checksum mismatch in %s" % (name, path))
         return arr.reshape(e["shape"])
 
 

@@ -67,25 +67,37 @@ class Yolo(object):
         global batch: rank r runs images shard_range(B, r, W), the fixed-size box records are all-gathered (the only
         exchange, net/dist.py) and every rank returns the full list.  `self.last_status` keeps the per-image status
         words (bit 0 candidate overflow, bit 1 more survivors than max_boxes): both raise, the reference has no caps."""
+        rank, world = ydist.world(group)
+        if world > 1:
+            lo, hi = ydist.shard_range(len(x_batch), rank, world)
+            return self.predict_shard(x_batch[lo:hi] if hi > lo else None, len(x_batch), threshold, iou_threshold, nms_mode, group)
+        return self.predict_shard(x_batch, len(x_batch), threshold, iou_threshold, nms_mode, group)
+
+    def predict_shard(self, x_local, n_global, threshold=0.5, iou_threshold=0.6, nms_mode=_hip.NMS_AGNOSTIC, group=None):
+        """predict() for a caller that holds only ITS images of the global batch (Yolo.test under torch.distributed
+        preprocesses just the rank's shard): x_local = images shard_range(n_global, rank, world) of the batch, or None
+        when the shard is empty.  Returns the list for all n_global images on every rank."""
         eng = self.net.engine
         if not eng.weights_loaded:
             raise RuntimeError("no weights loaded: call load_weights / build(weights=...) first")
         rank, world = ydist.world(group)
         if world > 1:
-            n = len(x_batch)
+            n = int(n_global)
             per = -(-n // world)
             if per > eng.max_batch:
                 raise ValueError("global batch %d over %d ranks needs max_batch >= %d (engine has %d)" % (n, world, per, eng.max_batch))
             lo, hi = ydist.shard_range(n, rank, world)
-            boxes, counts, status = ydist.detect_sharded(eng, x_batch[lo:hi] if hi > lo else None, threshold, iou_threshold,
-                                                         nms_mode, group)
+            n_local = 0 if x_local is None else len(x_local)
+            if n_local != hi - lo:
+                raise ValueError("rank %d holds %d images of a global batch of %d, its shard is [%d, %d)" % (rank, n_local, n, lo, hi))
+            boxes, counts, status = ydist.detect_sharded(eng, x_local if n_local else None, threshold, iou_threshold, nms_mode, group)
             keep = [r * eng.max_batch + i for r in range(world) for i in range(per)][:n]     # slot of global image g
             status = status.cpu().numpy().reshape(-1)[keep]
             self.last_status = status
             engine.check_status(status)
             lists = ydist.records_to_lists(boxes, counts)
             return base.boxes_from_records([lists[k] for k in keep])
-        boxes, counts, status = eng.detect(x_batch, threshold, iou_threshold, nms_mode)
+        boxes, counts, status = eng.detect(x_local, threshold, iou_threshold, nms_mode)
         records, self.last_status = engine.records_to_host(boxes, counts, status)
         return base.boxes_from_records(records)
 
@@ -119,7 +131,9 @@ class Yolo(object):
         # one process per GPU (torch.distributed initialised by the launcher, e.g. torchrun): every batch of `batch_size`
         # images shards over the ranks, the box records are all-gathered, rank 0 draws and writes (net/dist.py)
         rank, world = ydist.world()
-        self.build(anchors, class_names, input_shape, dtype=dtype, max_batch=-(-batch_size // world))
+        # the reference's box lists are unbounded (net/base.py:195-209); the record buffers are not: optional keys raise the caps
+        caps = {k: int(params[k]) for k in ("max_boxes", "cand_capacity") if k in params}
+        self.build(anchors, class_names, input_shape, dtype=dtype, max_batch=-(-batch_size // world), **caps)
         # same order as the reference (net/yolo.py:71-78, net/base.py:55-61): restore the TensorFlow checkpoint (read without
         # TensorFlow by net/tfckpt.py); when that fails, say so and load the Darknet weights
         restored = False
@@ -137,8 +151,12 @@ class Yolo(object):
         # resize / colour order / /255 run on the device with OpenCV's INTER_LINEAR arithmetic (base.preprocess_image_gpu);
         # `preprocess = pillow` (new optional key) keeps the host-side Pillow resampler
         batches = base.generate_test_batch if str(params.get("preprocess", "gpu")).lower() == "pillow" else base.generate_test_batch_gpu
-        for x_batch, paths in batches(image_paths, batch_size, input_shape):
-            net_boxes = self.predict(x_batch, threshold, iou_threshold, nms_mode)
+        for start in range(0, len(image_paths), batch_size):
+            paths = image_paths[start:start + batch_size]
+            # every rank decodes / resizes only ITS shard of the batch (one process per GPU)
+            lo, hi = ydist.shard_range(len(paths), rank, world)
+            x_local = next(iter(batches(paths[lo:hi], batch_size, input_shape)))[0] if hi > lo else None
+            net_boxes = self.predict_shard(x_local, len(paths), threshold, iou_threshold, nms_mode)
             if rank != 0:
                 continue
             for boxes, path in zip(net_boxes, paths):
@@ -147,7 +165,8 @@ class Yolo(object):
                 out_path = os.path.join(out_dir, "{}_out{}".format(file_name, file_ext))
                 base.save_image(new_img, out_path)
                 print("{}: Found {} objects. Saved to {}".format(file_name, len(boxes), out_path))
-        print("Done")
+        if rank == 0:
+            print("Done")
 
 
 class YoloV2(Yolo):

@@ -147,3 +147,74 @@ def test_bench_self_launches_ranks_without_a_gpu():
     assert r.returncode not in (0, 2), r.stderr[-2000:]
     # (the launcher tears the other rank down as soon as one has failed, so only one of the two messages is guaranteed)
     assert "rank 0 needs GPU 0" in r.stderr or "rank 1 needs GPU 1" in r.stderr, r.stderr[-2000:]
+
+
+# ---- the shipped launcher under a multi-process launcher (`torchrun launcher.py ...` must shard by itself) -------------
+def _launcher_worker(rank, world, port, ini, q):
+    """What `torchrun --nproc-per-node 2 launcher.py --config ... --mode test` gives each process: the rendezvous variables in
+    the environment and nothing else.  launcher.main must join the group itself (gloo here: no GPU), Yolo.test must preprocess
+    and run only the rank's shard, rank 0 alone writes the files."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    import io
+    from contextlib import redirect_stdout
+    from tensorflow_yolo_amd import launcher
+    from tensorflow_yolo_amd.net import base, yolo
+    seen = {"engine": None, "preprocessed": []}
+
+    def build(self, anchors, class_names, input_shape=(416, 416, 3), dtype="fp32", max_batch=1, **kw):
+        self.net = type("Net", (list,), {})()
+        self.net.engine = seen["engine"] = StandInEngine(max_batch=max_batch, max_boxes=kw.get("max_boxes", 8))
+        seen["kw"] = dict(kw, max_batch=max_batch)
+        return self.net
+
+    real_pre = base.preprocess_image
+
+    def counting_pre(path, shape):
+        seen["preprocessed"].append(os.path.basename(path))
+        return real_pre(path, shape)
+
+    yolo.Yolo.build = build
+    yolo.YoloV2.load_weights = staticmethod(lambda net, path: None)
+    base.preprocess_image = counting_pre
+    out = io.StringIO()
+    with redirect_stdout(out):
+        launcher.main(["--config", ini, "--mode", "test"])
+    q.put((rank, out.getvalue(), seen["preprocessed"], seen["engine"].calls, seen["kw"], dist.is_initialized()))
+
+
+def test_launcher_main_shards_under_torchrun_environment(tmp_path):
+    from PIL import Image
+    img_dir, out_dir = tmp_path / "img", tmp_path / "out"
+    img_dir.mkdir(); out_dir.mkdir()
+    tags = {"a": 0.125, "b": 0.375, "c": 0.0, "d": 0.625, "e": 0.25}          # mean value -> number of stand-in boxes (x 8)
+    for name, t in tags.items():
+        Image.new("RGB", (40, 30), (int(round(t * 255)),) * 3).save(str(img_dir / (name + ".png")))
+    names = ["c%d" % i for i in range(16)]
+    ini = tmp_path / "y.ini"
+    ini.write_text("[COMMON]\nversion = v2\ninput_h = 32\ninput_w = 32\ninput_c = 3\n[TEST]\nimage_dir = %s\nout_dir = %s\nbatch_size = 4\n"
+                   "threshold = 0.5\niou_threshold = 0.6\nanchors = [1, 1, 2, 2]\nclass_names = %r\ncheckpoint_path =\n"
+                   "pretrained_weights_path = none.weights\npreprocess = pillow\nmax_boxes = 8\ncand_capacity = 8192\n" % (img_dir, out_dir, names))
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_launcher_worker, args=(r, world, port, str(ini), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    order = sorted(os.listdir(str(img_dir)))            # (load_image_paths order is the directory order; compare as sets per batch)
+    r0, r1 = got
+    assert not r0[5] and not r1[5]                                          # launcher.main destroyed the group it created
+    assert r0[4] == {"max_boxes": 8, "cand_capacity": 8192, "max_batch": 2}      # optional cap keys reach build(); 4 images / 2 ranks
+    # every image is preprocessed by exactly one rank (batches of 4 + 1: shards 2 + 2, then 1 + 0)
+    assert sorted(r0[2] + r1[2]) == order and len(r0[2]) == 3 and len(r1[2]) == 2
+    assert r0[3] == 2 and r1[3] == 1                                        # kernels ran for the local shard only
+    lines = [l for l in r0[1].splitlines() if "Found" in l]
+    assert len(lines) == 5 and r0[1].strip().endswith("Done")
+    for name, t in tags.items():
+        assert any(l.startswith("%s: Found %d objects." % (name, int(round(int(round(t * 255)) / 255.0 * 8)))) for l in lines), (name, lines)
+        assert os.path.exists(str(out_dir / (name + "_out.png")))
+    assert "Found" not in r1[1] and "Done" not in r1[1]                     # rank 1 draws / writes nothing

@@ -50,7 +50,9 @@ def test_logits_fp16_bounded(kind, size, batch):
           % (kind, size, batch, e16, e32, np.abs(want32).max()))
     # fp16 rounding noise decorrelates through tens of layers; the emulation differs only in fp32 summation order
     assert e16 <= 2e-2, e16
-    assert e32 <= 0.15 * max(1.0, float(np.abs(want32).max())), e32
+    # absolute, near the measured behaviour (0.013 ... 0.036 on logits of up to +-23 through 23 / 75 fp16 layers): a bound
+    # relative to max|logit| would let 3.5 pass
+    assert e32 <= 0.1, e32
 
 
 def test_known_answer_sizes_from_the_library():
@@ -146,7 +148,7 @@ def test_multi_stream_forward_and_detect(streams):
         match_boxes(recs_a[i], [bb.astuple() for bb in want[i]])
     print("streams=%d: max|dlogit| %.2e, margins p %.2e iou %s, identity required %s, match %s"
           % (streams, e, rep["prob_margin"], rep["iou_margin"], rep["identity_required"], rep["box_set_match"]))
-    parity.assert_ok(rep, min_matched_frac=0.98)
+    parity.assert_ok(rep)
     ms = many.forward_timed(x)
     assert len(ms) == many.num_kernels and float(np.sum(ms)) > 0
 

@@ -161,3 +161,206 @@ def test_tfckpt_primitives():
     assert tfckpt._snappy_decompress(b"\x03\x08abc") == b"abc"
     for n in (0, 1, 127, 128, 300, 2 ** 40):
         assert tfckpt._varint(tfckpt._put_varint(n), 0) == (n, len(tfckpt._put_varint(n)))
+
+
+def _crc32c_bitwise(data):
+    """CRC-32C restated independently of net/tfckpt.py (bit by bit, reflected polynomial 0x82F63B78)."""
+    c = 0xffffffff
+    for b in bytearray(data):
+        c ^= b
+        for _ in range(8):
+            c = (c >> 1) ^ (0x82f63b78 & -(c & 1))
+    return c ^ 0xffffffff
+
+
+def _masked(crc):              # LevelDB/TensorFlow store crcs rotated right by 15 plus a constant (crc32c.h: Mask)
+    return (((crc >> 15) | (crc << 17)) + 0xa282ead8) & 0xffffffff
+
+
+def _vi(n):                    # protobuf / LevelDB varint
+    out = b""
+    while n >= 0x80:
+        out += bytes([(n & 0x7f) | 0x80])
+        n >>= 7
+    return out + bytes([n])
+
+
+def test_tf_checkpoint_hand_assembled_index(tmp_path):
+    """SURVEY 8f rank 4 / VERDICT r2 #8: a tensor-bundle index assembled BYTE BY BYTE here from the published format
+    (LevelDB table: prefix-compressed entries + restart array + 1-byte compression type + masked CRC32C per block, 48-byte
+    footer ending in the magic 0xdb4775248b80fb57; tensor_bundle.proto: BundleHeaderProto under key "", BundleEntryProto
+    {dtype = 1, shape = 2, shard_id = 3, offset = 4, size = 5, crc32c = 6 (fixed32)}) -- nothing from tfckpt.write_bundle.
+    It has what a real Saver checkpoint has and the round-trip test lacks: several data blocks, one of them SNAPPY-compressed,
+    shared-prefix keys across restart points, keys the graph does not own (global_step as an int64 scalar, Adam slots), two
+    data shards.  Still 'parity unpinned' against TensorFlow itself (absent here)."""
+    import struct
+    from tensorflow_yolo_amd.net import tfckpt
+    assert _crc32c_bitwise(b"123456789") == 0xe3069283 == tfckpt.crc32c(b"123456789")
+
+    # a two-conv graph in the reference's naming (net/layers.py:53-63): conv 0 with BN, conv 1 with bias
+    PL.conv2d_bn_act.reset()
+    net = [PL.input_layer([None, 8, 8, 3])]
+    net.append(PL.conv2d_bn_act(net[-1].out, 4, 3, 1, True, "leaky", False))
+    net.append(PL.conv2d_bn_act(net[-1].out, 6, 1, 1, False, "linear", False))
+    rng = np.random.RandomState(4)
+    t = {"yolo/conv2d_bn_act_0/beta": rng.randn(4), "yolo/conv2d_bn_act_0/gamma": rng.rand(4) + 0.5,
+         "yolo/conv2d_bn_act_0/moving_mean": rng.randn(4), "yolo/conv2d_bn_act_0/moving_variance": rng.rand(4) + 0.5,
+         "yolo/conv2d_bn_act_0/kernel": rng.randn(3, 3, 3, 4), "yolo/conv2d_bn_act_1/bias": rng.randn(6),
+         "yolo/conv2d_bn_act_1/kernel": rng.randn(1, 1, 4, 6)}
+    t = {k: v.astype("<f4") for k, v in t.items()}
+    extra = {"beta1_power": np.array(0.9, "<f4"), "global_step": np.array(1234567, "<i8"),
+             "yolo/conv2d_bn_act_0/kernel/Adam": np.zeros((3, 3, 3, 4), "<f4"), "yolo/conv2d_bn_act_0/kernel/Adam_1": np.ones((3, 3, 3, 4), "<f4")}
+    everything = dict(t, **extra)
+    names = sorted(everything)                      # a table's keys are sorted bytewise
+    # two data shards: variables of conv 1 live in shard 1
+    shard_of = {n: (1 if "act_1" in n else 0) for n in names}
+    blobs, offs = {0: b"", 1: b""}, {}
+    for n in names:
+        raw = everything[n].tobytes()
+        if shard_of[n] == 0 and len(blobs[0]) == 0:
+            blobs[0] += b"\0" * 0                   # (first tensor at offset 0: the offset field is then absent, proto3 default)
+        offs[n] = len(blobs[shard_of[n]])
+        blobs[shard_of[n]] += raw
+    prefix = str(tmp_path / "model.ckpt-7")
+    for sid in (0, 1):
+        open("%s.data-%05d-of-00002" % (prefix, sid), "wb").write(blobs[sid])
+
+    def entry(n):
+        a = everything[n]
+        dtype_id = {"<f4": 1, "<i8": 9}[a.dtype.str]
+        dims = b"".join(b"\x12" + _vi(len(d)) + d for d in (b"\x08" + _vi(s) for s in a.shape))      # TensorShapeProto.dim[].size
+        msg = b"\x08" + _vi(dtype_id) + b"\x12" + _vi(len(dims)) + dims
+        if shard_of[n]:
+            msg += b"\x18" + _vi(shard_of[n])
+        if offs[n]:
+            msg += b"\x20" + _vi(offs[n])
+        raw = a.tobytes()
+        return msg + b"\x28" + _vi(len(raw)) + b"\x35" + struct.pack("<I", _masked(_crc32c_bitwise(raw)))
+
+    header = b"\x08\x02" + b"\x1a\x02\x08\x01"       # BundleHeaderProto {num_shards = 2 (field 1), version {producer: 1} (field 3)}; little endian = default
+    pairs = [(b"", header)] + [(n.encode(), entry(n)) for n in names]
+
+    def block(items, restart_interval):
+        out, restarts, prev = b"", [], b""
+        for i, (k, v) in enumerate(items):
+            shared = 0
+            if i % restart_interval == 0:
+                restarts.append(len(out))
+            else:
+                while shared < min(len(prev), len(k)) and prev[shared] == k[shared]:
+                    shared += 1
+            out += _vi(shared) + _vi(len(k) - shared) + _vi(len(v)) + k[shared:] + v
+            prev = k
+        return out + b"".join(struct.pack("<I", r) for r in restarts) + struct.pack("<I", len(restarts))
+
+    def snappy(raw):
+        """raw Snappy: preamble varint(len), then a literal, one 2-byte-offset copy of a repeated run, and a literal."""
+        probe = b"yolo/conv2d_bn_act_0/"
+        first = raw.find(probe)
+        second = raw.find(probe, first + 1)
+        assert first >= 0 and second > first
+        ln = len(probe)
+
+        def literal(b):
+            assert 0 < len(b) <= 65536
+            if len(b) <= 60:
+                return bytes([(len(b) - 1) << 2]) + b
+            if len(b) <= 256:
+                return bytes([60 << 2, len(b) - 1]) + b
+            return bytes([61 << 2]) + struct.pack("<H", len(b) - 1) + b
+        copy = bytes([((ln - 1) << 2) | 2]) + struct.pack("<H", second - first)
+        return _vi(len(raw)) + literal(raw[:second]) + copy + literal(raw[second + ln:])
+
+    def with_trailer(body, ctype):
+        return body + bytes([ctype]) + struct.pack("<I", _masked(_crc32c_bitwise(body + bytes([ctype]))))
+
+    # three data blocks: [header + 3 keys] plain, [next 5 keys] SNAPPY with restart interval 1 (full keys repeat the prefix), [rest] plain
+    chunks = [(pairs[:4], 16, 0), (pairs[4:9], 1, 1), (pairs[9:], 2, 0)]
+    assert all(c[0] for c in chunks) and sum(len(c[0]) for c in chunks) == len(pairs)
+    f = b""
+    handles = []
+    for items, ri, ctype in chunks:
+        raw = block(items, ri)
+        body = snappy(raw) if ctype else raw
+        handles.append((items[-1][0], _vi(len(f)) + _vi(len(body))))
+        f += with_trailer(body, ctype)
+    meta = block([], 16)
+    meta_handle = _vi(len(f)) + _vi(len(meta))
+    f += with_trailer(meta, 0)
+    index = block(handles, 1)
+    footer = meta_handle + _vi(len(f)) + _vi(len(index))
+    f += with_trailer(index, 0)
+    f += footer + b"\0" * (40 - len(footer)) + struct.pack("<Q", 0xdb4775248b80fb57)
+    open(prefix + ".index", "wb").write(f)
+
+    b = tfckpt.Bundle(prefix)
+    assert b.num_shards == 2 and sorted(b.entries) == names
+    for n in names:
+        got = b.read(n)
+        assert got.dtype == everything[n].dtype.newbyteorder("=") and got.shape == everything[n].shape and np.array_equal(got, everything[n]), n
+    assert int(b.read("global_step")) == 1234567
+    # the Darknet stream in layer-list order: beta, gamma, mean, var, kernel [out][in][kh][kw] | bias, kernel (net/base.py:26-46)
+    want = np.concatenate([t["yolo/conv2d_bn_act_0/" + k] for k in ("beta", "gamma", "moving_mean", "moving_variance")] +
+                          [np.transpose(t["yolo/conv2d_bn_act_0/kernel"], (3, 2, 0, 1)).ravel(), t["yolo/conv2d_bn_act_1/bias"],
+                           np.transpose(t["yolo/conv2d_bn_act_1/kernel"], (3, 2, 0, 1)).ravel()])
+    assert np.array_equal(tfckpt.checkpoint_to_darknet(net, prefix), want)
+    # a flipped byte of tensor DATA is caught by the entry's crc32c (ADVICE r2: corrupted shards must not load silently)
+    raw = bytearray(blobs[1]); raw[5] ^= 0x40
+    open("%s.data-00001-of-00002" % prefix, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="data checksum"):
+        tfckpt.Bundle(prefix).read("yolo/conv2d_bn_act_1/bias")
+    # ... and a flipped byte inside the COMPRESSED block by the block trailer
+    bad = bytearray(f); bad[len(with_trailer(block(chunks[0][0], 16), 0)) + 7] ^= 0x01
+    open(prefix + ".index", "wb").write(bytes(bad))
+    with pytest.raises(ValueError, match="checksum"):
+        tfckpt.Bundle(prefix)
+
+
+def test_draw_boxes_content(tmp_path):
+    """SURVEY 8f rank 2 (reference net/base.py:212-226): the rectangle of thickness 3 sits on the box edges at the coordinates
+    scaled by the ORIGINAL image size, top-left clamped at 0, in COLORS[class_idx % 6] (the reference's BGR tuples, so RGB-swapped
+    here), the label text starts at the top-left corner, and every pixel away from boxes and labels is untouched."""
+    from PIL import Image
+    p = str(tmp_path / "flat.png")
+    W, H = 200, 120
+    Image.new("RGB", (W, H), (17, 17, 17)).save(p)
+    names = ["n%d" % i for i in range(9)]
+    boxes = [BoundingBox(x=0.5, y=0.5, w=0.4, h=0.5, class_idx=7, prob=0.8),          # inside: tl (60, 30), br (140, 90)
+             BoundingBox(x=0.1, y=0.2, w=0.3, h=0.6, class_idx=2, prob=0.5)]          # tl (-10, -12) -> clamped (0, 0), br (50, 60)
+    img = np.asarray(base.draw_boxes(p, boxes, names))
+    assert img.shape == (H, W, 3)
+
+    def rgb(ci):
+        b, g, r = base.COLORS[ci % len(base.COLORS)]
+        return (r, g, b)
+    c7, c2 = rgb(7), rgb(2)
+    assert c7 != c2 and len(base.COLORS) == 6
+    # box 1: cv2.rectangle thickness 3 = the corner coordinate +- 1: rows 29..31 and 89..91, columns 59..61 and 139..141
+    for y in (29, 30, 31, 89, 90, 91):
+        assert all(tuple(img[y, x]) == c7 for x in range(59, 142)), y
+    for x in (59, 60, 61, 139, 140, 141):
+        assert all(tuple(img[y, x]) == c7 for y in range(29, 92)), x
+    assert tuple(img[28, 100]) == (17, 17, 17) and tuple(img[32, 100]) == (17, 17, 17) and tuple(img[60, 100]) == (17, 17, 17)
+    assert tuple(img[60, 58]) == (17, 17, 17) and tuple(img[60, 62]) == (17, 17, 17) and tuple(img[60, 142]) == (17, 17, 17)
+    # box 2: top-left clamped at the image corner (the part at -1 falls off the image), bottom-right at (50, 60)
+    for x in range(0, 52):
+        assert all(tuple(img[y, x]) == c2 for y in (59, 60, 61)), x
+    for y in range(2, 62):
+        assert all(tuple(img[y, x]) == c2 for x in (49, 50, 51)), y
+        assert tuple(img[y, 0]) == c2 and tuple(img[y, 1]) == c2, y
+    assert tuple(img[30, 25]) == (17, 17, 17)
+    # labels: baseline at (tl.x, tl.y - 10): box 1's text sits in rows ~9..20 right of x = 60; box 2's baseline is at y = -10,
+    # off the image -- the reference loses that label too
+    lab1 = img[6:22, 60:140].reshape(-1, 3).astype(int)
+    changed = (lab1 != 17).any(axis=1)
+    assert changed.sum() >= 40                                                          # "n7 0.800" (anti-aliased glyphs)
+    toward = (lab1[changed] - 17) * (np.array(c7) - 17)                                 # every touched pixel moves towards the class colour
+    assert (toward >= 0).all() and (toward > 0).any(axis=1).all()
+    assert (img[23:28, 62:139] == 17).all()                                             # nothing between the baseline and the box
+    # everything outside the two outlines' bounding rectangles and the label strip is the original image
+    mask = np.ones((H, W), bool)
+    mask[29:92, 59:142] = False; mask[0:62, 0:52] = False; mask[4:24, 59:142] = False
+    assert (img[mask] == 17).all()
+    inner = np.zeros((H, W), bool)
+    inner[32:89, 62:139] = True; inner[2:59, 2:49] = True                              # box interiors stay as they were
+    assert (img[inner] == 17).all()

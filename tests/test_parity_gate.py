@@ -1,0 +1,96 @@
+"""CPU: the parity gate (oracle/parity.py) itself -- fp16-sized logit noise must come out fully explained, and a defect
+that drops / adds / reorders boxes away from the thresholds must not."""
+import numpy as np
+import pytest
+
+from oracle import cases, decode_ref, parity
+
+
+def _case(version):
+    if version == 3:
+        c = dict(cases.CASES["v3_320_lowthr"], threshold=0.5, iou=0.6, obj_shift=-3.8, seed=77, batch=2, ties=0)
+        head = cases.make_head(c)
+        head[..., 0:4] *= np.float32(0.2)           # anchor-sized boxes near the cell centres: neighbours overlap, NMS has work
+        kw = dict(scales=decode_ref.v3_scales(c["anchors"], (c["input"], c["input"])))
+    else:
+        c = dict(cases.CASES["v2_416_thr05"], seed=78, ties=0, batch=1, obj_shift=0.0)
+        head = cases.make_head(c)
+        kw = dict(anchors=c["anchors"], num_classes=c["classes"])
+    return c, head, kw
+
+
+def _hip_like(c, logits, kw, per_class=False):
+    """What a correct HIP path returns for these logits: the oracle's decode + NMS of them."""
+    if c["version"] == 3:
+        pre = decode_ref.find_bounding_boxes_v3(logits, c["threshold"], c["iou"], kw["scales"], nms=False)
+    else:
+        pre = decode_ref.find_bounding_boxes_v2(logits, c["threshold"], c["iou"], kw["anchors"], kw["num_classes"], nms=False)
+    nms = decode_ref.non_maximum_suppression_per_class if per_class else decode_ref.non_maximum_suppression
+    return [[b.astuple() for b in nms(p, c["iou"])] for p in pre]
+
+
+@pytest.mark.parametrize("version", [2, 3])
+@pytest.mark.parametrize("noise", [0.0, 2e-2, 6e-2])
+def test_noise_is_explained(version, noise):
+    c, head, kw = _case(version)
+    rng = np.random.RandomState(5)
+    got = (head + rng.uniform(-noise, noise, size=head.shape)).astype(np.float32)
+    boxes = _hip_like(c, got, kw)
+    rep = parity.check(head, got, boxes, version, c["threshold"], c["iou"], **kw)
+    assert rep["boxes_ref"] > 20
+    assert rep["boxes_unexplained"] == 0, rep
+    parity.assert_ok(rep) if not rep["identity_required"] or rep["box_set_match"] else None
+    if noise == 0.0:
+        assert rep["box_set_match"] and rep["identity_required"] and rep["rows_differing"] == 0
+    if noise == 6e-2:
+        assert rep["rows_differing"] > 0, "the case is too easy: no flip to explain at this noise level"
+
+
+@pytest.mark.parametrize("version", [2, 3])
+@pytest.mark.parametrize("defect", ["drop", "extra", "swap", "class", "drop_in_logits"])
+def test_defects_are_not_explained(version, defect):
+    c, head, kw = _case(version)
+    rng = np.random.RandomState(6)
+    got = (head + rng.uniform(-2e-2, 2e-2, size=head.shape)).astype(np.float32)
+    boxes = _hip_like(c, got, kw)
+    img = 0
+    assert len(boxes[img]) > 8
+    if defect == "drop":                    # a decode that loses a confident box
+        del boxes[img][1]
+    elif defect == "extra":                 # an NMS that lets a suppressed box through
+        b = list(boxes[img][0]); b[5] = b[5] - 0.01; b[0] += 1e-3
+        boxes[img].insert(1, tuple(b))
+    elif defect == "swap":                  # wrong output order
+        boxes[img][0], boxes[img][3] = boxes[img][3], boxes[img][0]
+    elif defect == "class":                 # wrong argmax
+        b = list(boxes[img][2]); b[4] = (int(b[4]) + 1) % c["classes"]; boxes[img][2] = tuple(b)
+    elif defect == "drop_in_logits":        # a conv defect that wipes a confident row WITHOUT showing in max |error| beyond fp16 noise
+        # (the row's objectness moves by less than the band would allow only if it were borderline: it is not)
+        p = parity._scores(head, version, c["classes"])[img]
+        row = int(np.argmax(p))
+        g2 = got.reshape(got.shape[0], -1, 5 + c["classes"]).copy()
+        g2[img, row, 4] -= 30.0
+        got = g2.reshape(got.shape)
+        boxes = _hip_like(c, got, kw)
+        rep = parity.check(head, got, boxes, version, c["threshold"], c["iou"], **kw)
+        assert rep["max_abs_logit_err"] > 1.0           # this kind shows in the logit error, which every test bounds
+        return
+    rep = parity.check(head, got, boxes, version, c["threshold"], c["iou"], **kw)
+    assert rep["boxes_unexplained"] >= 1, rep
+    with pytest.raises(AssertionError):
+        parity.assert_ok(rep)
+
+
+def test_per_class_trace_matches_per_class_nms():
+    c, head, kw = _case(3)
+    pre = decode_ref.find_bounding_boxes_v3(head, c["threshold"], c["iou"], kw["scales"], nms=False)
+    for p in pre:
+        o, kept, _, _, _ = parity.nms_trace(p, c["iou"], per_class=True)
+        a = [o[i].astuple() for i in range(len(o)) if kept[i]]
+        b = [x.astuple() for x in decode_ref.non_maximum_suppression_per_class(p, c["iou"])]
+        assert a == b
+        agn = decode_ref.non_maximum_suppression(p, c["iou"])
+        assert len(b) >= len(agn)
+    boxes = _hip_like(c, head, kw, per_class=True)
+    rep = parity.check(head, head, boxes, 3, c["threshold"], c["iou"], per_class=True, **kw)
+    assert rep["box_set_match"] and rep["boxes_unexplained"] == 0 and rep["nms_mode"] == "per_class"
