@@ -91,13 +91,37 @@ __device__ __forceinline__ bool conv_decode_pixel(const ConvParams &p, int m, in
     return ok;
 }
 
-template <typename T, int TM, int TP, int PADQ = 0>
+// The folded-BN bias as the INITIAL value of the accumulators (the MFMA's C input) instead of an add in the epilogue: its
+// global load then waits under the prologue's DMA latency rather than in front of the epilogue, where nothing else of the
+// workgroup is in flight (block trace: ~0.7 us of a 3.6 us epilogue).  A lane owns couts cbase .. cbase + 4 TM - 1 of every
+// fragment (see conv_epilogue).  Kernels that start from it instantiate the epilogues with BIAS_IN_ACC.
+template <int TM, int TP>
+__device__ __forceinline__ void conv_init_acc_bias(const ConvParams &p, float4v (&acc)[TM][TP], int cbase) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const float4v bv = *reinterpret_cast<const float4v *>(p.bias + cbase + 4 * a);       // bias is padded to 128 couts
+#pragma unroll
+        for (int b = 0; b < TP; ++b) acc[a][b] = bv;
+    }
+}
+
+template <typename T, int TM, int TP, int PADQ = 0, bool BIAS_IN_ACC = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, float4v (&acc)[TM][TP], int cbase, int m_wave, int fr) {
     constexpr int CH = 4 * TM;
     constexpr int EPC = 16 / (int)sizeof(T);
     if (cbase >= p.Cout) return;
     const int nvalid = p.Cout - cbase < CH ? p.Cout - cbase : CH;
-    {   // bias + activation in place: the bias registers die before the residual chunks arrive
+    if constexpr (BIAS_IN_ACC) {
+#pragma unroll
+        for (int b = 0; b < TP; ++b)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = acc[a][b][j];
+                    acc[a][b][j] = p.leaky ? fmaxf(0.1f * x, x) : x;
+                }
+    } else {   // bias + activation in place: the bias registers die before the residual chunks arrive
         float bias[CH];
 #pragma unroll
         for (int i = 0; i < CH; ++i) bias[i] = p.bias[cbase + i];      // bias is padded to 128 couts
@@ -223,14 +247,24 @@ __device__ __forceinline__ void conv_store_partial(const ConvParams &p, float4v 
 // pixel's run of 64 consecutive floats (256 contiguous bytes) with one instruction.  OUT_NORMAL, no residual.
 constexpr int kStagePitch(int TM) { return 16 * TM + 4; }       // floats per pixel row of the slab (4 CH + pad)
 
-template <int TM, int TP, int PADQ = 0>
+template <int TM, int TP, int PADQ = 0, bool BIAS_IN_ACC = false>
 __device__ __forceinline__ void conv_epilogue_f32_staged(const ConvParams &p, float4v (&acc)[TM][TP], int cbase_wave, int m_wave,
                                                          int lane, float *slab) {
     constexpr int CH = 4 * TM;
     constexpr int PITCH = kStagePitch(TM);
     const int fr = lane & 15, fq = lane >> 4;
     const int cbase = cbase_wave + fq * CH;
-    {
+    if constexpr (BIAS_IN_ACC) {
+#pragma unroll
+        for (int b = 0; b < TP; ++b)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x = acc[a][b][j];
+                    acc[a][b][j] = p.leaky ? fmaxf(0.1f * x, x) : x;
+                }
+    } else {
         float bias[CH];
 #pragma unroll
         for (int i = 0; i < CH; ++i) bias[i] = p.bias[cbase + i];      // bias is padded to 128 couts

@@ -74,6 +74,11 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
     __shared__ __attribute__((aligned(16))) unsigned char smem[S * TILE_BYTES];
 
     const int tid = threadIdx.x;
+#ifdef YOLO_EXPERIMENT      // block trace (tools/trace_blocks.py); not in the product build
+    const unsigned long long t_start = p.trace ? wall_clock64() : 0ull;
+    const unsigned long long c_start = p.trace ? (unsigned long long)clock64() : 0ull;
+    unsigned long long t_first = 0ull;
+#endif
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -148,13 +153,9 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
         }
     };
 
-    float4v acc[TM][TP];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TP; ++b) acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
-
     const int fr = lane & 15, fq = lane >> 4;
+    float4v acc[TM][TP];
+    conv_init_acc_bias<TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH);     // the accumulators start from the bias (conv_common.h)
     const int fswz = lds_swz<BKC>(fr);      // fragment rows are 16-aligned + fr
     auto compute = [&](int stage) {
         const unsigned char *A = smem + stage * TILE_BYTES + (wm * TM * 16 + fr) * ROWB;
@@ -176,6 +177,9 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
 
     // ---- main loop: S-stage ring, counted vmcnt, raw barrier ------------------------------------
     const int KT = p.taps * tpt;
+#ifdef YOLO_EXPERIMENT
+    const unsigned long long t_setup = p.trace ? wall_clock64() : 0ull;
+#endif
 #pragma unroll
     for (int s = 0; s < S - 1; ++s)
         if (s < KT) issue_tile(s, s);
@@ -196,6 +200,7 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
         __builtin_amdgcn_sched_barrier(0);  // no ds_read / MFMA of the previous tile moves below the barrier (see conv_tap.hip)
         __builtin_amdgcn_s_barrier();       // tile kt visible to every wave; stage `fill` no longer read
 #ifdef YOLO_EXPERIMENT      // ablation flags (tools/ablate.py: results intentionally wrong); not in the product build
+        if (p.trace && kt == 0) t_first = wall_clock64();
         if (kt + S - 1 < KT && !(p.dbg & 1)) issue_tile(kt + S - 1, fill);
         if (!(p.dbg & 2)) compute(stage);
 #else
@@ -208,15 +213,27 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
 
 #ifdef YOLO_EXPERIMENT
     if (p.dbg & 4) return;             // experiment: no epilogue
+    const unsigned long long t_loop = p.trace ? wall_clock64() : 0ull;
 #endif
     if (p.out_f32 && !p.vec_out && p.outmode == OUT_NORMAL && !p.has_res) {      // head conv: coalesced float32 rows via LDS
         static_assert(8 * 16 * kStagePitch(TM) * 4 <= S * TILE_BYTES, "staging slabs must fit in the ring");
         __syncthreads();            // every wave is done reading the ring
-        conv_epilogue_f32_staged<TM, TP>(p, acc, n0 + wm * (TM * 16), m0 + wn * (TP * 16), lane,
+        conv_epilogue_f32_staged<TM, TP, 0, true>(p, acc, n0 + wm * (TM * 16), m0 + wn * (TP * 16), lane,
                                          reinterpret_cast<float *>(smem) + wave * 16 * kStagePitch(TM));
-        return;
+    } else {
+        conv_epilogue<T, TM, TP, 0, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, m0 + wn * (TP * 16), fr);
     }
-    conv_epilogue<T, TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH, m0 + wn * (TP * 16), fr);
+#ifdef YOLO_EXPERIMENT
+    if (p.trace && tid == 0) {          // YOLO_CONV_TRACE: phase timestamps (100 MHz) + placement of wave 0 of every block
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long *r = p.trace + (size_t)blockIdx.x * 8;
+        r[0] = t_start; r[1] = t_setup; r[2] = t_loop; r[3] = wall_clock64();
+        r[4] = __builtin_amdgcn_s_getreg(0xF804);      // HW_ID
+        r[5] = __builtin_amdgcn_s_getreg(0xF814);      // XCC_ID
+        r[6] = t_first;                                // first K tile landed (prologue DMA latency)
+        r[7] = (unsigned long long)clock64() - c_start;
+    }
+#endif
 }
 
 struct DmaCfg {
@@ -363,6 +380,46 @@ const char *dma_cfg_name(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg
     X(7, 1, 8, 4, 4, 2, 4, 4) \
     X(14, 2, 4, 4, 2, 3, 4, 6)
 
+static hipError_t launch_dma_tile(const ConvParams &p, int cfg, hipStream_t s) {
+    const dim3 grid((unsigned)p.n_blocks), block(512);
+    switch (cfg) {
+#define X(id, ...) case id: hipLaunchKernelGGL((conv_igemm_dma_kernel<__VA_ARGS__>), grid, block, 0, s, p); break;
+        YOLO_DMA_VARIANTS(X)
+#undef X
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+#ifdef YOLO_EXPERIMENT
+// experiment: YOLO_CONV_TRACE=<file> appends, for every LDS-DMA / tap-reuse launch, a header {blocks, M, Cout, cin_chunks, H, W, cfg,
+// ksize * 10 + stride} and 8 uint64 per block (see the kernels); synchronous, for tools/trace_blocks.py only
+static hipError_t launch_traced(ConvParams p, int cfg, hipStream_t s) {
+    const char *tf = getenv("YOLO_CONV_TRACE");
+    unsigned long long *dev = nullptr;
+    const size_t bytes = (size_t)p.n_blocks * 64;
+    if (hipMalloc((void **)&dev, bytes) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipMemset(dev, 0, bytes);
+    p.trace = dev;
+    hipError_t e = is_tap_cfg(cfg) ? launch_conv_tap(p, tap_variant(cfg), s) : launch_dma_tile(p, cfg, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    std::vector<unsigned long long> host((size_t)p.n_blocks * 8);
+    if (e == hipSuccess) e = hipMemcpy(host.data(), dev, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (e == hipSuccess) {
+        if (FILE *fp = fopen(tf, "ab")) {
+            const unsigned long long hdr[8] = {(unsigned long long)p.n_blocks, (unsigned long long)p.M, (unsigned long long)p.Cout,
+                                               (unsigned long long)p.cin_chunks, (unsigned long long)p.H, (unsigned long long)p.W,
+                                               (unsigned long long)cfg, (unsigned long long)(p.ksize * 10 + p.stride)};
+            fwrite(hdr, 8, 8, fp);
+            fwrite(host.data(), 8, host.size(), fp);
+            fclose(fp);
+        }
+    }
+    return e;
+}
+#endif
+
 hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
     if (cfg <= 0 || cfg >= kNumCfgs) return hipErrorInvalidValue;
     ConvParams p = p0;
@@ -391,42 +448,15 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
         p.Mq = (int)mq;
         p.n_blocks = (int)qblocks;
         conv_set_divisors(p, p.cin_chunks / k.bkc);
-        // experiment: YOLO_CONV_TRACE=<file> appends, for every tap-reuse launch, a header {blocks, M, Cout, cin_chunks,
-        // H, W, cfg, 0} and 8 uint64 per block (see the kernel); synchronous, for tools/trace_blocks.py only
 #ifdef YOLO_EXPERIMENT
-        if (const char *tf = getenv("YOLO_CONV_TRACE")) {
-            unsigned long long *dev = nullptr;
-            const size_t bytes = (size_t)p.n_blocks * 64;
-            if (hipMalloc((void **)&dev, bytes) != hipSuccess) return hipErrorOutOfMemory;
-            p.trace = dev;
-            hipError_t e = launch_conv_tap(p, tap_variant(cfg), s);
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
-            std::vector<unsigned long long> host((size_t)p.n_blocks * 8);
-            if (e == hipSuccess) e = hipMemcpy(host.data(), dev, bytes, hipMemcpyDeviceToHost);
-            (void)hipFree(dev);
-            if (e == hipSuccess) {
-                if (FILE *fp = fopen(tf, "ab")) {
-                    const unsigned long long hdr[8] = {(unsigned long long)p.n_blocks, (unsigned long long)p.M, (unsigned long long)p.Cout,
-                                                       (unsigned long long)p.cin_chunks, (unsigned long long)p.H, (unsigned long long)p.W,
-                                                       (unsigned long long)cfg, 0ull};
-                    fwrite(hdr, 8, 8, fp);
-                    fwrite(host.data(), 8, host.size(), fp);
-                    fclose(fp);
-                }
-            }
-            return e;
-        }
+        if (getenv("YOLO_CONV_TRACE")) return launch_traced(p, cfg, s);
 #endif
         return launch_conv_tap(p, tap_variant(cfg), s);
     }
-    const dim3 grid((unsigned)blocks), block(512);
-    switch (cfg) {
-#define X(id, ...) case id: hipLaunchKernelGGL((conv_igemm_dma_kernel<__VA_ARGS__>), grid, block, 0, s, p); break;
-        YOLO_DMA_VARIANTS(X)
-#undef X
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
+#ifdef YOLO_EXPERIMENT
+    if (getenv("YOLO_CONV_TRACE")) return launch_traced(p, cfg, s);
+#endif
+    return launch_dma_tile(p, cfg, s);
 }
 
 // the name rocprofv3's kernel trace prints for the kernel a tile id runs (yolo_kernel_info.symbol)

@@ -178,15 +178,23 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     // float32: second-level accumulator (conv_common.h: flush_acc); only the TP <= 2 tiles have the registers for it at
     // two workgroups per CU, so those are the float32 tiles (kTapF32)
     float4v acc2[F32 ? TM : 1][F32 ? TP : 1];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TP; ++b) {
-            acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
-            if (F32) acc2[F32 ? a : 0][F32 ? b : 0] = float4v{0.f, 0.f, 0.f, 0.f};
-        }
-
     const int fr = lane & 15, fq = lane >> 4;
+    // the accumulators start from the bias (conv_common.h: conv_init_acc_bias); split-K partial sums carry none
+    if constexpr (SPLITK) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TP; ++b) acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
+    } else {
+        conv_init_acc_bias<TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH);
+    }
+    if constexpr (F32) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TP; ++b) acc2[F32 ? a : 0][F32 ? b : 0] = float4v{0.f, 0.f, 0.f, 0.f};
+    }
+
     const int a_frag = (wm * TM * 16 + fr) * ROWB + (((fq ^ tap_swz_w(fr)) & 3) << 4);
     const int rb = wn * TP * FROW + fr;     // patch row of this lane's position for tap (0, 0)
 
@@ -268,7 +276,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         conv_store_partial<TM, TP, MODE>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr, (int)blockIdx.y);
         return;
     } else {
-        conv_epilogue<T, TM, TP, MODE>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
+        conv_epilogue<T, TM, TP, MODE, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
     }
 #ifdef YOLO_EXPERIMENT
     if (p.trace && tid == 0) {          // YOLO_CONV_TRACE: phase timestamps (100 MHz) + placement of wave 0 of every block

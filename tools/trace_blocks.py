@@ -37,16 +37,24 @@ while pos < len(raw):
     hdr = raw[pos:pos + 8]; pos += 8
     nb = int(hdr[0])
     rec = raw[pos:pos + nb * 8].reshape(nb, 8); pos += nb * 8
-    layers[tuple(int(v) for v in hdr[1:7])] = rec
+    layers[tuple(int(v) for v in hdr[1:8])] = rec
+TAP_CFGS = (8, 9, 10, 11, 12, 13, 15)
+ONLY = os.environ.get("TRACE_ONLY", "")           # e.g. "k1" (1x1 layers), "s2" (stride-2 layers)
 for key, rec in layers.items():
-    M, cout, cpt, H, W, cfg = key
+    M, cout, cpt, H, W, cfg, ks = key
+    if ONLY == "k1" and ks // 10 != 1: continue
+    if ONLY == "s2" and ks % 10 != 2: continue
+    if ONLY == "tap" and cfg not in TAP_CFGS: continue
     t = rec[:, :4].astype(np.int64)
     t0 = t[:, 0].min()
     t = (t - t0) / 100.0                      # us (100 MHz)
     hw = rec[:, 4]; xcc = rec[:, 5] & 0xf
     cu = ((hw >> 8) & 0xf).astype(int); se = ((hw >> 13) & 0x7).astype(int); sh = ((hw >> 12) & 1).astype(int)
     cuid = (xcc.astype(int) * 8 + se) * 32 + sh * 16 + cu
-    print("== layer %dx%d cin %d -> %d, tile %d: %d blocks on %d CUs, span %.1f us" % (H, W, cpt * 8, cout, cfg, len(rec), len(set(cuid)), t[:, 3].max()))
+    print("== layer %dx%d k%d/s%d cin %d -> %d, tile %d: %d blocks on %d CUs, span %.1f us" % (H, W, ks // 10, ks % 10, cpt * 8, cout, cfg, len(rec), len(set(cuid)), t[:, 3].max()))
+    if cfg not in TAP_CFGS and ks:
+        f = (rec[:, 6].astype(np.int64) - rec[:, 1].astype(np.int64)) / 100.0
+        print("   first K tile landed (after setup) mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f us" % (f.mean(), *np.percentile(f, [10, 50, 90])))
     cyc = rec[:, 7].astype(np.float64)
     print("   shader clock during the blocks: %.0f MHz (median of cycles / wall time)" % np.median(cyc / ((rec[:, 3] - rec[:, 0]).astype(np.float64) / 100.0)))
     d = np.stack([t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]], 1)
@@ -54,7 +62,7 @@ for key, rec in layers.items():
         print("   %-16s mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f us" % (nm, d[:, i].mean(), *np.percentile(d[:, i], [10, 50, 90])))
     # occupancy over time
     T = t[:, 3].max()
-    grid = np.linspace(0, T, 41)
+    grid = np.linspace(0, T, int(os.environ.get("TRACE_BINS", "21")))
     print("   time(us)  in-setup  in-loop  in-epilogue  (workgroups)")
     for g in grid[:-1]:
         a = ((t[:, 0] <= g) & (g < t[:, 1])).sum(); b = ((t[:, 1] <= g) & (g < t[:, 2])).sum(); c = ((t[:, 2] <= g) & (g < t[:, 3])).sum()
