@@ -7,10 +7,12 @@
 //
 // Persistent workgroups (8 waves, two per CU) keep the layer-2 weights (9 taps x 64 couts x 64 B, swizzled rows) in
 // LDS and walk tiles of 8 x 16 layer-2 outputs x all 64 couts; per tile:
-//   phase 0  the 19 x 35 x 3 float32 input patch, fetched into registers one tile ahead, -> fp16 in LDS (zero
-//            outside the image = layer 1's padding);
-//   phase 1  layer 1 on MFMA for the 17 x 33 positions layer 2 needs: K = 27 (kh, kw, c) padded to one 32-deep
-//            k-step, B fragments gathered from the patch, bias + leaky, ZERO outside the image (= layer 2's
+//   phase 0  the 19 x 35 x 3 float32 input patch, fetched into registers one tile ahead, -> fp16 in LDS as 8-byte
+//            pixels R G B 0 (zero outside the image = layer 1's padding);
+//   phase 1  layer 1 on MFMA for the 17 x 33 positions layer 2 needs: K = 27 (kh, kw, c) spread over two 32-deep
+//            k-steps so that a lane's 8 k are two WHOLE neighbouring pixels of one patch row = 16 contiguous bytes
+//            (two ds_read_b64; the 2-byte gather of round 1/2 cost 8 conflicting ds_read_u16 + packing per lane:
+//            SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.32), bias as the MFMA's C input, leaky, ZERO outside the image (= layer 2's
 //            padding), fp16, written as 64-byte rows of an LDS patch whose columns are de-interleaved by parity, so
 //            that the stride-2 taps of 16 consecutive outputs read 16 consecutive rows;
 //   phase 2  layer 2: 9 taps x one k-step, A = weight tile of the tap, B = patch rows (shift-invariant swizzle of
@@ -43,7 +45,8 @@ constexpr int P1X = 2 * TX + 1;             // 33 layer-1 columns
 constexpr int NPOS = P1Y * P1X;             // 561 layer-1 positions
 constexpr int NGRP = (NPOS + 15) / 16;      // 36 groups of 16 positions
 constexpr int INY = P1Y + 2, INX = P1X + 2; // 19 x 35 input pixels
-constexpr int IN_LD = 112;                  // halfs per input patch row (35 * 3 = 105, padded)
+constexpr int IN_PX = 36;                   // pixels per input patch row (35 used + one that only zero weights meet)
+constexpr int IN_LD = IN_PX * 4;            // halfs per input patch row: a pixel is R G B 0 = 8 bytes
 constexpr int EVEN_COLS = (P1X + 1) / 2;    // 17 even columns come first in a patch row block
 constexpr int W2_BYTES = 9 * 64 * 64;
 constexpr int P_BYTES = NGRP * 16 * 64;
@@ -78,35 +81,39 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
             stem_dma16(rs_w, sW + i * 1024, off);
         }
     }
-    // layer-1 weights as MFMA A fragments: tile t, row rho = fr holds channel 8*(rho>>2) + 4t + (rho&3); k = 8 fq + j
-    uint4v a1[2];
-    float bias1[8];
+    // layer-1 weights as MFMA A fragments: tile t, row rho = fr holds channel 8*(rho>>2) + 4t + (rho&3).  K layout of
+    // k-step s: lane group fq, element j -> patch row kh = (s == 0 ? fq >> 1 : 2), pixel pw = 2 (fq & 1) + (j >> 2),
+    // channel c = j & 3; weight zero where pw == 3, c == 3, or (s == 1 and fq >= 2)
+    uint4v a1[2][2];
+    float4v bias1[2];
     {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int ch = 8 * (fr >> 2) + 4 * t + (fr & 3);
-            T h[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 8 * fq + j;
-                const float w = p.w1[(k < 27 ? k : 26) * 32 + ch];      // unconditional load, then select
-                h[j] = k < 27 ? (T)w : (T)0.f;
+            for (int st = 0; st < 2; ++st) {
+                T h[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kh = st == 0 ? (fq >> 1) : 2, pw = 2 * (fq & 1) + (j >> 2), c = j & 3;
+                    const bool live = pw < 3 && c < 3 && (st == 0 || fq < 2);
+                    const float w = p.w1[(live ? (kh * 3 + pw) * 3 + c : 0) * 32 + ch];      // unconditional load, then select
+                    h[j] = live ? (T)w : (T)0.f;
+                }
+                __builtin_memcpy(&a1[t][st], h, 16);
             }
-            __builtin_memcpy(&a1[t], h, 16);
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) bias1[i] = p.b1[8 * fq + i];
+        bias1[0] = *reinterpret_cast<const float4v *>(p.b1 + 8 * fq);          // channels 8 fq + {0..3}: C input of tile 0
+        bias1[1] = *reinterpret_cast<const float4v *>(p.b1 + 8 * fq + 4);
         if (tid < 64) sBias[tid] = p.b2[tid];
         else if (tid < 96 && p.w3) sBias[tid] = p.b3[tid - 64];
+        // the fourth half of every pixel and the 36th pixel of every row are never written again: zero (finite) for good
+        for (int i = tid; i < INY * IN_PX; i += 512) *reinterpret_cast<unsigned long long *>(sIn + i * 4) = 0ull;
     }
-    // per-lane K decode of the B fragment: k = 8 fq + j -> offset kh * IN_LD + (kw * 3 + c) inside the input patch
-    int koff[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = 8 * fq + j;
-        const int kh = k / 9;
-        koff[j] = k < 27 ? kh * IN_LD + (k - 9 * kh) : 0;
-    }
+    // per-lane patch offsets (halfs) of the two B fragments: step 0 row fq >> 1, step 1 row 2 (lane groups 2, 3 meet zero
+    // weights there and re-read rows 0 / 1: finite values)
+    const int boff0 = (fq >> 1) * IN_LD + 2 * (fq & 1) * 4;
+    const int boff1 = (fq < 2 ? 2 : (fq >> 1)) * IN_LD + 2 * (fq & 1) * 4;
     const int a_frag = fr * 64 + (((fq ^ stem_swz_w(fr)) & 3) << 4);
     // optional layer 3 (1x1 64->32): the lane already owns 16 channels of its pixel after layer 2, and an MFMA sums over
     // k in any order, so k-step ks takes channels 16 fq + 8 ks + j straight from the lane's registers (no LDS round
@@ -152,6 +159,7 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
     int tile = blockIdx.x;
     fetch_input(tile);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // weights landed (once), first input patch in registers
+    __syncthreads();                                    // the zero fill of the input patch is ordered before the first tile's stores
     for (; tile < p.n_tiles; tile += gridDim.x) {
         int n, oy0, ox0;
         tile_origin(tile, n, oy0, ox0);
@@ -161,7 +169,8 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
         for (int it = 0; it < NIN; ++it) {
             const int idx = it * 512 + tid;
             const int row = idx / (INX * 3), col = idx - row * (INX * 3);
-            if (idx < INY * INX * 3) sIn[row * IN_LD + col] = (T)in_r[it];
+            const int px = col / 3;
+            if (idx < INY * INX * 3) sIn[row * IN_LD + px * 4 + (col - 3 * px)] = (T)in_r[it];
         }
         __syncthreads();    // input patch visible; every wave is past phase 2 of the previous tile (patch P is free)
         if (tile + (int)gridDim.x < p.n_tiles) fetch_input(tile + gridDim.x);
@@ -172,31 +181,30 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
             const bool live = pp < NPOS;
             const int pc = live ? pp : NPOS - 1;
             const int py = pc / P1X, px = pc - py * P1X;
-            const T *src = sIn + py * IN_LD + px * 3;
-            T h[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const T v = src[koff[j]];
-                h[j] = (8 * fq + j < 27) ? v : (T)0.f;
-            }
-            uint4v b;
-            __builtin_memcpy(&b, h, 16);
-            float4v d0 = mma_chunk<T>(a1[0], b, float4v{0.f, 0.f, 0.f, 0.f});
-            float4v d1 = mma_chunk<T>(a1[1], b, float4v{0.f, 0.f, 0.f, 0.f});
+            const T *src = sIn + py * IN_LD + px * 4;
+            typedef unsigned long long u64;
+            const u64 b00 = *reinterpret_cast<const u64 *>(src + boff0), b01 = *reinterpret_cast<const u64 *>(src + boff0 + 4);
+            const u64 b10 = *reinterpret_cast<const u64 *>(src + boff1), b11 = *reinterpret_cast<const u64 *>(src + boff1 + 4);
+            uint4v b0, b1;
+            b0.x = (unsigned)b00; b0.y = (unsigned)(b00 >> 32); b0.z = (unsigned)b01; b0.w = (unsigned)(b01 >> 32);
+            b1.x = (unsigned)b10; b1.y = (unsigned)(b10 >> 32); b1.z = (unsigned)b11; b1.w = (unsigned)(b11 >> 32);
+            float4v d0 = mma_chunk<T>(a1[0][0], b0, bias1[0]);
+            float4v d1 = mma_chunk<T>(a1[1][0], b0, bias1[1]);
+            d0 = mma_chunk<T>(a1[0][1], b1, d0);
+            d1 = mma_chunk<T>(a1[1][1], b1, d1);
             // lane: channels 8 fq + {0..3} (d0) and 8 fq + {4..7} (d1) of position fr
             const int gy = y1_0 + py, gx = x1_0 + px;
             const bool inside = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             T o[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v0 = d0[j] + bias1[j], v1 = d1[j] + bias1[4 + j];
-                v0 = fmaxf(0.1f * v0, v0);
-                v1 = fmaxf(0.1f * v1, v1);
-                o[j] = (T)(inside ? v0 : 0.f);
-                o[4 + j] = (T)(inside ? v1 : 0.f);
+                const float v0 = leaky01(d0[j]), v1 = leaky01(d1[j]);
+                o[j] = (T)v0;
+                o[4 + j] = (T)v1;
             }
             uint4v u;
             __builtin_memcpy(&u, o, 16);
+            if (!inside) u = uint4v{0u, 0u, 0u, 0u};        // layer 2's zero padding (tiles on the image border only)
             const int rowP = py * P1X + ((px & 1) ? EVEN_COLS + (px >> 1) : (px >> 1));
             if (live) *reinterpret_cast<uint4v *>(sP + rowP * 64 + ((fq ^ stem_swz_p(rowP)) << 4)) = u;
         }
@@ -231,7 +239,7 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float v = acc[a][j];
-                o[4 * a + j] = (T)fmaxf(0.1f * v, v);
+                o[4 * a + j] = (T)leaky01(v);
             }
         uint4v u0, u1;
         __builtin_memcpy(&u0, o, 16);
@@ -251,8 +259,8 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float v0 = d0[j], v1 = d1[j];
-                o3[j] = (T)fmaxf(0.1f * v0, v0);
-                o3[4 + j] = (T)fmaxf(0.1f * v1, v1);
+                o3[j] = (T)leaky01(v0);
+                o3[4 + j] = (T)leaky01(v1);
             }
             uint4v u3;
             __builtin_memcpy(&u3, o3, 16);

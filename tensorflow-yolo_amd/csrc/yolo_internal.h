@@ -66,6 +66,21 @@ __host__ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) 
     return (t + ((n - t) >> f.sh1)) >> f.sh2;
 }
 
+// leaky ReLU 0.1 (net/layers.py:6,50-51: tf.nn.leaky_relu = max(alpha x, x)) as TWO instructions: fmaxf() on an MFMA result
+// makes hipcc put a canonicalising `v_max x, x` in front of the real one (three instructions per value).  Used where the kernel is VALU-bound (stem.hip:
+// -5 %); the conv epilogues keep fmaxf(), whose instructions the compiler schedules freely (the opaque asm cost them +1 %,
+// the staged float32 head epilogue +19 %: profiles/r03_ablation.md).  Same value for every non-NaN input.
+__host__ __device__ __forceinline__ float leaky01(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    const float y = 0.1f * x;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(y), "v"(x));
+    return r;
+#else
+    return x > 0.1f * x ? x : 0.1f * x;
+#endif
+}
+
 struct ConvParams {
     const void *in;            // base of the input BUFFER (view offsets are folded into byte offsets)
     const void *wgt;
