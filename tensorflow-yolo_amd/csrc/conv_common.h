@@ -57,16 +57,16 @@ __device__ __forceinline__ void flush_acc(float4v (&acc)[TM][TP], float4v (&acc2
 // PADQ (conv_tap.hip): the pixel index is a position q of the padded-linear grid [n][y <= H][x <= W] (one shared
 // zero row / column between image rows and images); pad positions are computed but never stored.
 // PADQ 0: dense pixel index; 1: padded-linear position (conv_tap.hip MODE 1); 2: position inside 2-D tiles of
-// (256 / 16) x 16 pixels (conv_tap.hip MODE 2: qW = tiles per tile row, qHW = tiles per image)
+// TH x 16 pixels, TH = 16 or 8 (conv_tap.hip MODE 2: qW = tiles per tile row, qHW = tiles per image, t2_shift = log2(16 TH))
 template <int PADQ>
 __device__ __forceinline__ bool conv_decode_pixel(const ConvParams &p, int m, int &n, int &rem, int &oy, int &ox) {
     bool ok;
     if (PADQ == 2) {
-        const int tile = m >> 8, l = m & 255;
+        const int tile = m >> p.t2_shift, l = m & ((1 << p.t2_shift) - 1);
         n = (int)fdiv((uint32_t)tile, p.dqHW);
         const int r = tile - n * p.qHW;
         const int ty = (int)fdiv((uint32_t)r, p.dqW);
-        oy = ty * 16 + (l >> 4);
+        oy = (ty << (p.t2_shift - 4)) + (l >> 4);
         ox = (r - ty * p.qW) * 16 + (l & 15);
         ok = m < p.Mq && oy < p.Ho && ox < p.Wo;
         if (!ok) { n = 0; oy = 0; ox = 0; }

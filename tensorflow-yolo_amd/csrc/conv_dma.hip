@@ -259,11 +259,12 @@ static const DmaCfg kCfgs[] = {
     {64, 256, 2, 1.00f, "64x256,tap9,2d,x2", 4},       // 13: ... and Cout <= 64
     {128, 128, 3, 1.00f, "128x128,K32,S3,x3", 4},      // 14: conv_dma again: 48 KiB LDS, <= 80 VGPRs: three workgroups per CU (short-K 1x1 layers)
     {256, 224, 1, 1.00f, "256x224,tap9", 4},           // 15: conv_tap.hip variant 6 (see there)
+    {128, 128, 3, 1.00f, "128x128,tap9,2d,x3", 4},     // 16: conv_tap.hip variant 7: 8 x 16 2-D tile, three workgroups per CU
 };
-static const int kNumCfgs = 16;
+static const int kNumCfgs = 17;
 static const int kFirstTapCfg = 8, kLastTapCfg = 13;
-static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || cfg == 15; }
-static inline int tap_variant(int cfg) { return cfg == 15 ? 6 : cfg - kFirstTapCfg; }     // conv_tap.hip variant of a tap cfg
+static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || cfg == 15 || cfg == 16; }
+static inline int tap_variant(int cfg) { return cfg == 15 ? 6 : cfg == 16 ? 7 : cfg - kFirstTapCfg; }     // conv_tap.hip variant of a tap cfg
 bool dma_cfg_is_tap(int cfg) { return is_tap_cfg(cfg); }
 bool dma_cfg_f32_ok(int cfg) { return is_tap_cfg(cfg) && conv_tap_f32_ok(tap_variant(cfg)); }
 
@@ -306,6 +307,7 @@ static const TileCost kCost[] = {
     {1.00f, 1.00f, 0.60f, 5.8f},        // 13: 64x256 tap reuse, 2-D tiles (chosen by rule below)
     {1.10f, 1.50f, 0.70f, 8.0f},        // 14: 128x128 K32 S3, three per CU: 1x1 layers only (short K, memory / latency bound)
     {1.05f, 1.05f, 1.05f, 18.0f},       // 15: 256x224 tap reuse (7/8 of the 256x256 tile's loop)
+    {0.0f, 0.0f, 0.0f, 0.0f},           // 16: 128x128 2-D tap reuse, three per CU (chosen by rule)
 };
 
 int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W, bool tap_only) {
@@ -320,11 +322,12 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
         if (M >= 8192 && dma_cfg_valid(13, cout, cin_chunks, v1_ok, ksize, stride, W)) return 13;
         return !tap_only && dma_cfg_valid(7, cout, cin_chunks, v1_ok, ksize, stride, W) && M >= 8192 ? 7 : fallback;
     }
-    // wide maps with a short K (152x152 64 -> 128 at batch 32: 172 us on the 128 x 128 tap tile, 181 on the per-tap LDS-DMA tile
-    // the model picks, r02 sweep): the tap-reuse tile with the smallest patch wins where the launch is bandwidth-bound
+    // wide maps with a short K (152x152 64 -> 128 at batch 32, round 3, after the bias moved into the accumulators and the 2-D
+    // tile lost its 36 spilled registers: 155 us on the 128 x 256 2-D tap tile, 161 on the 128 x 128 2-D tile at three
+    // workgroups per CU, 175 on the padded-linear 128 x 128 tile, 181 on the per-tap LDS-DMA tile the model picks)
     if (!tap_only && taps == 9 && stride == 1 && W > 110 && cout <= 128 && cin_chunks <= 8 && M >= 262144 &&
-        dma_cfg_valid(11, cout, cin_chunks, v1_ok, ksize, stride, W))
-        return 11;
+        dma_cfg_valid(12, cout, cin_chunks, v1_ok, ksize, stride, W))
+        return 12;
     const double k64 = taps * cin_chunks / 8.0;         // 64-deep K tiles
     int best = fallback;
     double best_t = 1e300;
@@ -334,12 +337,12 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
         if (tap_only && !dma_cfg_f32_ok(c)) continue;
         if (c == 12 && W <= 110) continue;      // the padded-linear tiles fit and measured faster (104x104: 70 vs 84 us)
         if (c == 14 && taps != 1) continue;     // measured 10-20 % slower than the larger tiles on every 3x3 layer
-        if (c == 7 || c == 13 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
+        if (c == 7 || c == 13 || c == 16 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
         const DmaCfg &k = kCfgs[c];
         // tap-reuse tiles walk the padded position grid: (H+1)(W+1) positions per image (square maps assumed here)
         long long Meff = M;
         if (is_tap_cfg(c)) {
-            if (conv_tap_is2d(tap_variant(c))) { const long long t = (W + 15) / 16; Meff = (long long)M * t * t * 256 / ((long long)W * W); }
+            if (conv_tap_is2d(tap_variant(c))) { const long long th = k.nb / 16, tx = (W + 15) / 16, ty = (W + th - 1) / th; Meff = (long long)M * tx * ty * k.nb / ((long long)W * W); }
             else Meff = (long long)M * (W + 1) * (W + 1) / ((long long)W * W);
         }
         const long long blocks = (Meff + k.nb - 1) / k.nb * ((cout + k.na - 1) / k.na);
@@ -434,10 +437,13 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
     conv_set_divisors(p, p.cin_chunks / k.bkc);
     if (is_tap_cfg(cfg)) {          // padded-linear position grid: one shared pad column per row, one pad row per image
         long long mq;
-        if (conv_tap_is2d(tap_variant(cfg))) {     // 16 x 16 tiles: qW = tiles per tile row, qHW = tiles per image
+        if (conv_tap_is2d(tap_variant(cfg))) {     // TH x 16 tiles (TH = positions per block / 16): qW = tiles per tile row, qHW = tiles per image
+            const int th = k.nb / 16;
+            p.t2_shift = th == 16 ? 8 : 7;
+            if (th != 16 && th != 8) return hipErrorInvalidValue;
             p.qW = (p.W + 15) / 16;
-            p.qHW = p.qW * ((p.H + 15) / 16);
-            mq = (long long)(p.M / p.HoWo) * p.qHW * 256;
+            p.qHW = p.qW * ((p.H + th - 1) / th);
+            mq = (long long)(p.M / p.HoWo) * p.qHW * k.nb;
         } else {
             p.qW = p.W + 1;
             p.qHW = (p.H + 1) * (p.W + 1);

@@ -74,7 +74,10 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     constexpr int NB = WN * TP * 16;
     constexpr int JA_TOT = NA / 16;         // weight DMA wave-instructions per tap
     constexpr int JA = (JA_TOT + NW - 1) / NW;      // per wave (a 64-cout tile has 4: waves 4..7 carry none)
-    constexpr int PW = 24;                  // MODE 2: patch row pitch in positions
+    // MODE 2: patch row pitch in positions.  24 (a multiple of 8) keeps the swizzle phase of every fragment row equal, so the
+    // fragment offsets are immediates; the three-workgroups-per-CU tile (OCC 6) takes the minimal pitch 18 to fit its two patch
+    // buffers into a third of the LDS and pays one address computation per fragment and tap instead
+    constexpr int PW = (MODE == 2 && OCC >= 6) ? 18 : 24;
     constexpr int FROW = MODE == 2 ? PW : 16;       // patch rows between consecutive fragments of a wave
     constexpr int JP = (PRG + NW - 1) / NW; // patch DMA wave-instructions per wave per slice
     constexpr int CH = 4 * TM;
@@ -83,7 +86,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     static_assert(WM * WN == NW, "eight waves");
     static_assert(JA_TOT % NW == 0 || JA_TOT < NW, "weight tile must split evenly over the waves (or be smaller than them)");
     static_assert(MODE == 1 || PRG * 16 >= (NB / 16 + 2) * PW, "patch buffer too small for the 2-D tile");
-    if constexpr (F32 && TP > 2) return;    // never launched (launch_conv_tap refuses): no registers for the second accumulator
+    if constexpr (F32 && (TP > 2 || OCC >= 6)) return;     // never launched (launch_conv_tap refuses): no registers for the second accumulator
     if constexpr (SPLITK && !(WM == 2 && WN == 4 && TM == 4 && TP == 2 && MODE == 1)) return;      // split-K: the 128 x 128 tile only
     __shared__ __attribute__((aligned(16))) unsigned char smem[S * A_BYTES + 2 * P_BYTES];
     unsigned char *const smemP = smem + S * A_BYTES;
@@ -206,7 +209,14 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
 #pragma unroll
         for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const uint4v *>(A + a * 16 * ROWB);
 #pragma unroll
-        for (int b = 0; b < TP; ++b) fb[b] = *reinterpret_cast<const uint4v *>(B + b * FROW * ROWB);
+        for (int b = 0; b < TP; ++b) {
+            if constexpr (MODE == 2 && (FROW & 7) != 0) {       // the swizzle phase differs from fragment row to fragment row
+                const int Rb = R + b * FROW;
+                fb[b] = *reinterpret_cast<const uint4v *>(smemP + buf * P_BYTES + (Rb << 6) + ((fq << 4) ^ ((Rb & 4) << 3)));
+            } else {
+                fb[b] = *reinterpret_cast<const uint4v *>(B + b * FROW * ROWB);
+            }
+        }
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -296,12 +306,14 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
 // variants: 0 = 128 couts x 256 positions, 1 = 256 x 256 (one workgroup per CU), 2 = 128 x 192, 3 = 128 x 128 (smaller
 // position tiles fill the 512 workgroup slots of the chip better on small feature maps), all padded-linear;
 // 4 = 128 x (16 x 16) and 5 = 64 x (16 x 16) 2-D tiles for maps wider than 78 (any width)
-static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224};
-static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17};
-static const int kTapVariants = 7;
-static const bool kTapF32[] = {false, false, false, true, false, true, false};      // float32 tiles: TP <= 2 (second-level accumulator)
+// 7 = 128 couts x (8 x 16) 2-D tile at THREE workgroups per CU (48 KiB LDS, <= 80 VGPRs) for wide maps with a short K, where
+// a workgroup spends as long in setup + epilogue as in its K loop (152 x 152 64 -> 128: block trace in profiles/r03_ablation.md)
+static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224, 128};
+static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17, 12};
+static const int kTapVariants = 8;
+static const bool kTapF32[] = {false, false, false, true, false, true, false, false};      // float32 tiles: TP <= 2 (second-level accumulator)
 bool conv_tap_splitk_ok(int variant) { return variant == 3; }      // the 128 x 128 tile has the split-K instantiation
-bool conv_tap_is2d(int variant) { return variant == 4 || variant == 5; }
+bool conv_tap_is2d(int variant) { return variant == 4 || variant == 5 || variant == 7; }
 bool conv_tap_f32_ok(int variant) { return variant >= 0 && variant < kTapVariants && kTapF32[variant]; }
 bool conv_tap_fits(int variant, int W) {
     if (variant < 0 || variant >= kTapVariants) return false;
@@ -318,7 +330,8 @@ bool conv_tap_fits(int variant, int W) {
     X(3, 2, 4, 4, 2, 28, 4, 1) \
     X(4, 2, 4, 4, 4, 27, 4, 2) \
     X(5, 1, 8, 4, 2, 27, 4, 2) \
-    X(6, 4, 2, 4, 7, 17, 2, 1)
+    X(6, 4, 2, 4, 7, 17, 2, 1) \
+    X(7, 2, 4, 4, 2, 12, 6, 2)
 
 const char *conv_tap_symbol(int variant, bool f32) {
     switch (variant) {

@@ -109,6 +109,7 @@ struct ConvParams {
     float *part;
     int dbg;                   // experiment flags (YOLO_CONV_DBG): 1 skip steady-state DMA, 2 skip MFMA phase
     int qW, qHW, Mq;           // conv_tap.hip: padded-linear pixel grid, row stride W+1, image stride (H+1)(W+1), total
+    int t2_shift;              // conv_tap.hip MODE 2: log2 of the positions per 2-D tile (8: 16 x 16, 7: 8 x 16)
     float *obj_out;            // head convs (staged float32 epilogue): compact objectness logits [B][obj_rows] or null
     int obj_width, obj_rows, obj_row0, obj_na;     // 5 + classes; rows per image; first row of this scale; anchors per cell
     unsigned long long *trace; // conv_tap.hip: per-block phase timestamps (YOLO_CONV_TRACE experiment) or null
