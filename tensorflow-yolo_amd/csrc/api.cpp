@@ -26,6 +26,7 @@ static int fail(int code, const std::string &msg) {
 
 namespace {
 bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile);
+size_t splitk_slab_bytes(const yolo_net *net);
 }
 
 extern "C" {
@@ -60,6 +61,9 @@ int yolo_net_create(const yolo_layer_desc *layers, int n_layers, const yolo_net_
     if (net->opt.force_tile > 0)        // test / tuning hook: one tile id on every conv that accepts it
         for (Kernel &k : net->kernels)
             if (k.kind == K_CONV && k.stem < 2 && conv_tile_valid(net, k, net->opt.force_tile - 1)) k.tile = net->opt.force_tile - 1;
+    // the split-K slab is the last region of the workspace (plan.cpp reserves nothing for it): sized from the launches that can split
+    net->splitk_bytes = splitk_slab_bytes(net) * (size_t)net->arenas;
+    net->workspace_bytes = net->splitk_off + net->splitk_bytes;
     *out = net;
     return YOLO_OK;
 }
@@ -234,9 +238,8 @@ bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile) {
 // would leave most of the chip idle (<= 128 workgroups) and K is long, the K range is cut into `ks` splits of `ku` units
 // (conv_tap.hip: channel slices, conv.hip: K tiles) so that ~384 workgroups exist; their float32 partial sums meet in
 // splitk_reduce_kernel.  Returns 1 when the launch stays whole.
-int choose_ksplit(const yolo_net *net, const Kernel &k, const ConvParams &p, int tile, int &ku) {
+int choose_ksplit(const Kernel &k, const ConvParams &p, int tile, size_t slab_bytes, int &ku) {
     ku = 0;
-    const size_t slab_bytes = net->splitk_bytes / (size_t)net->arenas;      // concurrent parts (streams) must not share a slab
     if (!slab_bytes || p.M <= 0) return 1;
     long long blocks;
     int units, min_units;
@@ -271,24 +274,69 @@ int choose_ksplit(const yolo_net *net, const Kernel &k, const ConvParams &p, int
     return (units + ku - 1) / ku;       // every split owns at least one unit
 }
 
-// tile < 0: heuristic (choose_dma_cfg); 0: 4-wave kernel of conv.hip; > 0: conv_dma.hip tile id
-hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParams &p0, int tile, hipStream_t s, int arena = 0) {
+// What one conv launch runs: the tile (0 = the 4-wave kernel of conv.hip with the planner's cfg, > 0 = conv_dma.hip tile id) and
+// the K split (ks = 1: whole K).  tile_req < 0: the rules of choose_dma_cfg.  One function for the launch path, the workspace
+// sizing (split-K slab) and yolo_net_kernel_info, so what is reported is what runs.
+struct ConvPick { int tile, ks, ku; };
+const size_t kSplitkSlabMax = (size_t)64 << 20;     // per arena
+
+ConvPick pick_conv(const yolo_net *net, const Kernel &k, const ConvParams &p, int tile_req, size_t slab_bytes) {
+    int tile = tile_req;
     if (!dma_eligible(net, k) || (tile > 0 && !conv_tile_valid(net, k, tile))) tile = 0;
-    else if (tile < 0) tile = choose_dma_cfg(p0.M, k.cout, k.cpt, p0.taps, k.has_res, true, k.stride, k.in.W, net->opt.dtype == YOLO_DTYPE_F32);
-    ConvParams p = p0;
+    else if (tile < 0) tile = choose_dma_cfg(p.M, k.cout, k.cpt, p.taps, k.has_res, true, k.stride, k.in.W, net->opt.dtype == YOLO_DTYPE_F32);
     int ku = 0;
-    int ks = choose_ksplit(net, k, p, tile, ku);
+    int ks = choose_ksplit(k, p, tile, slab_bytes, ku);
     // a 3x3/1 layer small enough for split-K runs it on the 128 x 128 tap tile (the one with the split-K instantiation), whatever
     // tile the cost model would pick for the whole-K launch
     if (ks <= 1 && tile > 0 && dma_cfg_is_tap(tile) && tile != 11 && conv_tile_valid(net, k, 11)) {
         int ku11 = 0;
-        const int ks11 = choose_ksplit(net, k, p, 11, ku11);
+        const int ks11 = choose_ksplit(k, p, 11, slab_bytes, ku11);
         if (ks11 > 1) { tile = 11; ks = ks11; ku = ku11; }
     }
+    return ConvPick{tile, ks, ku};
+}
+
+// the shape fields pick_conv reads, for a batch, without device pointers (workspace sizing, kernel_info)
+void conv_shape_params(const yolo_net *net, const Kernel &k, int batch, ConvParams &p) {
+    memset(&p, 0, sizeof p);
+    const yolo_layer_desc &d = net->layers[k.src_layer].d;
+    p.H = k.in.H; p.W = k.in.W;
+    p.Ho = net->layers[k.src_layer].H; p.Wo = net->layers[k.src_layer].W; p.HoWo = p.Ho * p.Wo;
+    p.M = (int)((long long)batch * p.HoWo);
+    p.Cout = k.cout;
+    p.ksize = d.ksize; p.stride = d.stride; p.taps = d.ksize * d.ksize;
+    p.ktiles = k.ktiles; p.cin_chunks = k.cpt;
+}
+
+// float32 partial-sum slab one arena needs for ANY batch up to its share of max_batch (a net built for batch 32 also runs
+// the short last batch of a TEST directory, where the small maps do split): 0 when no launch ever splits
+size_t splitk_slab_bytes(const yolo_net *net) {
+    const int per = (net->opt.max_batch + net->arenas - 1) / net->arenas;
+    size_t need = 0;
+    for (const Kernel &k : net->kernels) {
+        if (k.kind != K_CONV || k.stem >= 2) continue;
+        for (int b = 1; b <= per; ++b) {
+            ConvParams p;
+            conv_shape_params(net, k, b, p);
+            const ConvPick pk = pick_conv(net, k, p, k.tile, kSplitkSlabMax);
+            if (pk.ks > 1) {
+                const size_t bytes = (size_t)pk.ks * (size_t)p.M * (size_t)((p.Cout + 127) / 128 * 128) * 4;
+                if (bytes > need) need = bytes;
+            }
+        }
+    }
+    return (need + 4095) / 4096 * 4096;
+}
+
+hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParams &p0, int tile_req, hipStream_t s, int arena = 0) {
+    const size_t slab = net->splitk_bytes / (size_t)net->arenas / 256 * 256;      // concurrent parts (streams) must not share a slab
+    const ConvPick pk = pick_conv(net, k, p0, tile_req, slab);
+    const int tile = pk.tile, ks = pk.ks, ku = pk.ku;
+    ConvParams p = p0;
     if (ks > 1) {
         p.ksplit = ks; p.kunits = ku;
         p.cout_pad = (p.Cout + 127) / 128 * 128;
-        p.part = reinterpret_cast<float *>(net->dev_ws + net->splitk_off + (size_t)arena * (net->splitk_bytes / (size_t)net->arenas / 256 * 256));
+        p.part = reinterpret_cast<float *>(net->dev_ws + net->splitk_off + (size_t)arena * slab);
     }
     hipError_t e = tile > 0 ? launch_conv_dma(p, tile, s) : launch_conv(p, net->opt.dtype, k.cfg, k.perchunk != 0, s);
     if (e != hipSuccess || ks <= 1) return e;
@@ -595,17 +643,30 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
             }
             return YOLO_OK;
         }
-        int tile = 0;       // which kernel runs at max_batch (bench.py runs at max_batch)
-        if (dma_eligible(net, k))
-            tile = k.tile >= 0 ? k.tile : choose_dma_cfg((net->opt.max_batch + net->arenas - 1) / net->arenas * li.H * li.W, k.cout, k.cpt, k.ksize * k.ksize, k.has_res, true, k.stride, k.in.W, net->opt.dtype == YOLO_DTYPE_F32);
+        // which kernel runs at max_batch (bench.py runs at max_batch): the same decision the launch path takes
+        ConvParams sp;
+        conv_shape_params(net, k, (net->opt.max_batch + net->arenas - 1) / net->arenas, sp);
+        const ConvPick pk = pick_conv(net, k, sp, k.tile, net->splitk_bytes / (size_t)net->arenas / 256 * 256);
+        const int tile = pk.tile;
+        const bool f32net = net->opt.dtype == YOLO_DTYPE_F32;
         if (tile > 0) {
             out->variant = 8 + tile;
             snprintf(out->name, sizeof out->name, "conv_igemm_dma<%s,%s>", t, dma_cfg_name(tile));
-            set_symbol(dma_cfg_symbol(tile, net->opt.dtype == YOLO_DTYPE_F32));
+            std::string sym = dma_cfg_symbol(tile, f32net);
+            if (pk.ks > 1) {        // the split-K instantiation of the tap kernel (its last template argument)
+                const size_t at = sym.rfind(", false>(");
+                if (at != std::string::npos) sym.replace(at, 9, ", true>(");
+            }
+            set_symbol(sym);
         } else {
             set_symbol(conv_symbol(net->opt.dtype, k.cfg, k.perchunk != 0));
             snprintf(out->name, sizeof out->name, "conv_igemm<%s,N%d,%s>", t, k.cfg == CFG_N128 ? 128 : k.cfg == CFG_N64 ? 64 : 32,
                      k.perchunk ? "perchunk" : "uniform");
+        }
+        if (pk.ks > 1) {            // two launches: K splits into the float32 slab, then splitk_reduce_kernel (sum + fused epilogue)
+            const size_t n = strlen(out->name);
+            snprintf(out->name + n, sizeof out->name - n, "+splitK%d", pk.ks);
+            out->bytes += 2.0 * pk.ks * (double)li.H * li.W * ((k.cout + 127) / 128 * 128) * 4.0;      // partial sums written + read once
         }
     } else if (k.kind == K_FIRST) {
         out->ksize = 3; out->stride = 1; out->cin = 3; out->cout = k.cout; out->out_h = k.out.H; out->out_w = k.out.W;

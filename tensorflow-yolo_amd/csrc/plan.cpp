@@ -614,10 +614,10 @@ int plan_network(yolo_net *net, const yolo_layer_desc *layers, int n, std::strin
     net->obj_off = off;
     net->obj_bytes = net->head.n_classes > 0 ? (size_t)net->opt.max_batch * (net->out_count / (size_t)(5 + net->head.n_classes)) * 4 : 0;
     off += roundup_sz(net->obj_bytes, 4096);
-    // split-K slabs: ksplit x pixels x cout_pad float32 with ksplit x tiles <= ~512 workgroups of >= 128 x 128 -> <= 34 MB
+    // split-K slabs (float32 partial sums of the convs whose launch would leave the chip idle): last region of the workspace,
+    // sized by yolo_net_create from the launches that can actually split (api.cpp: splitk_slab_bytes) -- 0 for most big-batch nets
     net->splitk_off = off;
-    net->splitk_bytes = (size_t)64 << 20;
-    off += net->splitk_bytes;
+    net->splitk_bytes = 0;
     net->workspace_bytes = off;
     return YOLO_OK;
 }
