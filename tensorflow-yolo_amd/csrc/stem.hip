@@ -129,10 +129,15 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
         }
     }
 
-    // input patch of a tile: thread -> NIN elements (row, col) of the 19 x 105 float block, fetched into registers
-    // one tile ahead (the HBM latency hides behind the previous tile's two MFMA phases)
-    constexpr int NIN = (INY * INX * 3 + 511) / 512;
+    // input patch of a tile (19 rows x 105 floats), fetched into registers one tile ahead (the HBM latency hides behind the
+    // previous tile's two MFMA phases): four patch rows per pass, 128 threads per row (105 used), so a thread's column, pixel
+    // and channel never change and its row advances by 4 -- no division, LDS offsets are immediates
+    constexpr int NIN = (INY + 3) / 4;
     float in_r[NIN];
+    const int in_col = tid & 127, in_row0 = tid >> 7;
+    const bool in_col_ok = in_col < INX * 3;
+    const int in_px = in_col / 3;
+    T *const in_dst = sIn + in_row0 * IN_LD + in_px * 4 + (in_col - 3 * in_px);
     auto tile_origin = [&](int tile, int &n, int &oy0, int &ox0) {
         const uint32_t tyx = fdiv((uint32_t)tile, p.dtx);
         const int tx = (int)((uint32_t)tile - tyx * (uint32_t)p.tiles_x);
@@ -144,14 +149,14 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
         int n, oy0, ox0;
         tile_origin(tile, n, oy0, ox0);
         const float *img = p.in + (long long)n * p.in_img_stride;
-        const int gy0 = 2 * oy0 - 2, gx3_0 = (2 * ox0 - 2) * 3;
+        const int gy0 = 2 * oy0 - 2 + in_row0, gx3 = (2 * ox0 - 2) * 3 + in_col;
+        const bool xok = in_col_ok && (unsigned)gx3 < (unsigned)(3 * p.W);
+        const int w3 = 3 * p.W;
 #pragma unroll
         for (int it = 0; it < NIN; ++it) {
-            const int idx = it * 512 + tid;
-            const int row = idx / (INX * 3), col = idx - row * (INX * 3);
-            const int gy = gy0 + row, gx3 = gx3_0 + col;
-            const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx3 < (unsigned)(3 * p.W);
-            const float v = img[ok ? ((long long)gy * p.W) * 3 + gx3 : 0];      // always-valid address, then select
+            const int gy = gy0 + 4 * it;
+            const bool ok = xok && (unsigned)gy < (unsigned)p.H && (4 * it + in_row0 < INY);
+            const float v = img[ok ? gy * w3 + gx3 : 0];      // always-valid address, then select (an image is < 2^31 floats)
             in_r[it] = ok ? v : 0.f;
         }
     };
@@ -166,12 +171,8 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
         const int y1_0 = 2 * oy0 - 1, x1_0 = 2 * ox0 - 1;      // layer-1 position of patch element (0, 0)
         // float32 -> fp16 (same operand rounding as the unfused first-layer kernel)
 #pragma unroll
-        for (int it = 0; it < NIN; ++it) {
-            const int idx = it * 512 + tid;
-            const int row = idx / (INX * 3), col = idx - row * (INX * 3);
-            const int px = col / 3;
-            if (idx < INY * INX * 3) sIn[row * IN_LD + px * 4 + (col - 3 * px)] = (T)in_r[it];
-        }
+        for (int it = 0; it < NIN; ++it)
+            if (in_col_ok && 4 * it + in_row0 < INY) in_dst[4 * it * IN_LD] = (T)in_r[it];
         __syncthreads();    // input patch visible; every wave is past phase 2 of the previous tile (patch P is free)
         if (tile + (int)gridDim.x < p.n_tiles) fetch_input(tile + gridDim.x);
 
