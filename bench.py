@@ -61,7 +61,8 @@ def make_model(kind, size, batch, dtype, seed=0, streams=0, max_boxes=256, **eng
     w = synth.darknet_stream(net, seed=seed, num_classes=ncls, head_gain=hg, obj_bias=0.0)
     model.build(anchors, names, (size, size, 3), dtype=dtype, max_batch=batch, weights=w, streams=streams, max_boxes=max_boxes, **engine_kw)
     # data-dependent objectness prior (uses the product's own forward): a realistic handful of candidates
-    w = synth.calibrate_model(model, synth.synthetic_input(min(batch, 2), size, size, 3, seed=999), frac)
+    # (at the workload's own batch: a rocprofv3 trace of this command then holds launches of that batch only)
+    w = synth.calibrate_model(model, synth.synthetic_input(batch, size, size, 3, seed=999), frac)
     return model, w, anchors, ncls
 
 

@@ -14,7 +14,9 @@ for wl in ${2:-v3-608-b32-fp16 v2-416-b16-fp16 tiny-v2-voc-416-b64-fp32}; do
   grep "rc=" gpurun_out/${TAG}_pmc_$wl.log
   if [ $rc -ge 124 ]; then echo "pmc timed out: stopping"; exit $rc; fi
   # keep only what the summaries need (the raw CSVs are large)
-  python3 tools/pmc_traffic.py gpurun_out/${TAG}_pmc_$wl $wl gpurun_out/${TAG}_traffic.json > gpurun_out/${TAG}_traffic_$wl.txt 2>&1
+  # profiles/traffic.json travels with the snapshot (gpurun_out/ does not): update it in place, then copy it out for the merge back
+  python3 tools/pmc_traffic.py gpurun_out/${TAG}_pmc_$wl $wl profiles/traffic.json > gpurun_out/${TAG}_traffic_$wl.txt 2>&1
+  cp profiles/traffic.json gpurun_out/${TAG}_traffic.json
   python3 tools/pmc_summary.py gpurun_out/${TAG}_pmc_$wl 24 > gpurun_out/${TAG}_pmc_summary_$wl.jsonl 2>&1
   f=$(find gpurun_out/${TAG}_prof_$wl -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_kernel_stats_$wl.csv
   cp gpurun_out/${TAG}_prof_$wl/bench_under_rocprof.log gpurun_out/${TAG}_bench_under_rocprof_$wl.log 2>/dev/null
