@@ -165,10 +165,19 @@ struct Ptrs {
     unsigned char *view_ptr(const View &v) const { return buf_base(v.buf) + (size_t)(v.base + v.coff) * esz(v); }
 };
 
+// 16-byte epilogue accesses are possible when every stride of the view is chunk-aligned (planned buffers start 4096-byte aligned
+// inside a 256-byte aligned workspace; a caller-owned tensor is checked at launch)
+void conv_vec_flags(const yolo_net *net, const Kernel &k, bool out_f32, int &vec_out, int &vec_res) {
+    const int epc = net->epc;
+    const int ch = k.cfg == CFG_N32 ? 8 : 16;
+    const int oepc = out_f32 ? 4 : epc;
+    vec_out = (k.cout % ch == 0) && (k.out.ld % oepc == 0) && ((k.out.base + k.out.coff) % oepc == 0) && (k.out.img_stride % oepc == 0);
+    vec_res = k.has_res && (k.cout % ch == 0) && (k.in2.ld % epc == 0) && (k.in2.coff % epc == 0) && (k.in2.img_stride % epc == 0);
+}
+
 // conv launch parameters for one planned kernel at the given batch
 int make_conv_params(yolo_net *net, const Kernel &k, const Ptrs &P, int batch, ConvParams &p) {
     const int dtype = net->opt.dtype;
-    const int epc = net->epc;
     memset(&p, 0, sizeof p);
     const View &in = k.in;
     const long long in_bytes = (long long)batch * in.img_stride * net->esize;
@@ -191,6 +200,10 @@ int make_conv_params(yolo_net *net, const Kernel &k, const Ptrs &P, int batch, C
     p.out_ld = k.out.ld;
     p.out_img_stride = k.out.img_stride;
     p.out_f32 = k.out.f32 || dtype == YOLO_DTYPE_F32;
+    {   // extents for buffer-addressed epilogues (conv_tap.hip stream kernel): 0 when a tensor is not below 2 GiB
+        const long long ob = (long long)batch * k.out.img_stride * (p.out_f32 ? 4 : net->esize);
+        p.out_bytes = ob > 0 && ob <= 0x7ffffff0LL ? (uint32_t)ob : 0u;
+    }
     p.ksize = d.ksize; p.stride = d.stride; p.pad = (d.ksize - 1) / 2; p.taps = d.ksize * d.ksize;
     p.ktiles = k.ktiles;
     p.tiles_per_tap = k.perchunk ? 1 : k.cpt / 8;
@@ -199,10 +212,9 @@ int make_conv_params(yolo_net *net, const Kernel &k, const Ptrs &P, int batch, C
     p.wrow_bytes = (uint32_t)k.ktiles * 128;
     p.leaky = k.leaky; p.outmode = k.outmode; p.has_res = k.has_res;
     p.f32 = dtype == YOLO_DTYPE_F32;
-    const int ch = k.cfg == CFG_N32 ? 8 : 16;
-    const int oepc = p.out_f32 ? 4 : epc;
-    p.vec_out = (k.cout % ch == 0) && (k.out.ld % oepc == 0) && ((k.out.base + k.out.coff) % oepc == 0) &&
-                (k.out.img_stride % oepc == 0) && ((uintptr_t)P.buf_base(k.out.buf) % 16 == 0);
+    int vo = 0, vr = 0;
+    conv_vec_flags(net, k, p.out_f32 != 0, vo, vr);
+    p.vec_out = vo && ((uintptr_t)P.buf_base(k.out.buf) % 16 == 0);
     if (k.head && net->obj_bytes && net->head.n_classes > 0 && !p.vec_out && p.out_f32 && k.outmode == OUT_NORMAL && !k.has_res) {
         const int width = 5 + net->head.n_classes;
         const long long base = k.out.base + k.out.coff;
@@ -216,7 +228,9 @@ int make_conv_params(yolo_net *net, const Kernel &k, const Ptrs &P, int batch, C
         p.res = P.view_ptr(k.in2);
         p.res_ld = k.in2.ld;
         p.res_img_stride = k.in2.img_stride;
-        p.vec_res = (k.cout % ch == 0) && (k.in2.ld % epc == 0) && (k.in2.coff % epc == 0) && (k.in2.img_stride % epc == 0);
+        const long long rbytes = (long long)batch * k.in2.img_stride * net->esize;
+        p.res_bytes = rbytes > 0 && rbytes <= 0x7ffffff0LL ? (uint32_t)rbytes : 0u;
+        p.vec_res = vr;
     }
     return YOLO_OK;
 }
@@ -306,6 +320,14 @@ void conv_shape_params(const yolo_net *net, const Kernel &k, int batch, ConvPara
     p.Cout = k.cout;
     p.ksize = d.ksize; p.stride = d.stride; p.taps = d.ksize * d.ksize;
     p.ktiles = k.ktiles; p.cin_chunks = k.cpt;
+    p.f32 = net->opt.dtype == YOLO_DTYPE_F32;
+    p.out_f32 = k.out.f32 || p.f32;
+    p.outmode = k.outmode; p.has_res = k.has_res;
+    conv_vec_flags(net, k, p.out_f32 != 0, p.vec_out, p.vec_res);
+    const long long ob = (long long)batch * k.out.img_stride * (p.out_f32 ? 4 : net->esize);
+    p.out_bytes = ob > 0 && ob <= 0x7ffffff0LL ? (uint32_t)ob : 0u;
+    const long long rb = k.has_res ? (long long)batch * k.in2.img_stride * net->esize : 0;
+    p.res_bytes = rb > 0 && rb <= 0x7ffffff0LL ? (uint32_t)rb : 0u;
 }
 
 // float32 partial-sum slab one arena needs for ANY batch up to its share of max_batch (a net built for batch 32 also runs
@@ -652,7 +674,8 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         if (tile > 0) {
             out->variant = 8 + tile;
             snprintf(out->name, sizeof out->name, "conv_igemm_dma<%s,%s>", t, dma_cfg_name(tile));
-            std::string sym = dma_cfg_symbol(tile, f32net);
+            sp.ksplit = pk.ks;
+            std::string sym = dma_cfg_symbol_for(tile, f32net, sp);      // (the persistent form of the tap kernel where it takes the launch)
             if (pk.ks > 1) {        // the split-K instantiation of the tap kernel (its last template argument)
                 const size_t at = sym.rfind(", false>(");
                 if (at != std::string::npos) sym.replace(at, 9, ", true>(");

@@ -457,12 +457,21 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
 #ifdef YOLO_EXPERIMENT
         if (getenv("YOLO_CONV_TRACE")) return launch_traced(p, cfg, s);
 #endif
+        p.stream = 1;       // the persistent form of the tap kernel where it exists and applies (conv_tap.hip: conv_tap_stream_ok)
+#ifdef YOLO_EXPERIMENT
+        if (getenv("YOLO_NO_TAP_STREAM")) p.stream = 0;
+#endif
         return launch_conv_tap(p, tap_variant(cfg), s);
     }
 #ifdef YOLO_EXPERIMENT
     if (getenv("YOLO_CONV_TRACE")) return launch_traced(p, cfg, s);
 #endif
     return launch_dma_tile(p, cfg, s);
+}
+
+std::string dma_cfg_symbol_for(int cfg, bool f32, const ConvParams &p) {
+    if (is_tap_cfg(cfg) && conv_tap_stream_ok(p, tap_variant(cfg))) return conv_tap_stream_symbol(tap_variant(cfg));
+    return dma_cfg_symbol(cfg, f32);
 }
 
 // the name rocprofv3's kernel trace prints for the kernel a tile id runs (yolo_kernel_info.symbol)

@@ -50,6 +50,8 @@ __device__ __forceinline__ void tap_wait_vm() {
 
 __device__ __forceinline__ int tap_swz_w(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }   // weight tile: {0,2,3,1}[(r>>2)&3]
 
+constexpr int kTapStreamBiasFloats = 512;      // stream kernel: couts whose bias fits its LDS copy (2 KiB)
+
 }  // namespace
 
 // 8 waves = WM x WN; a wave owns TM*16 couts x TP*16 positions; PRG = 16-row groups of one patch buffer.
@@ -301,6 +303,256 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
 #endif
 }
 
+// ---- persistent ("stream") form ---------------------------------------------------------------------------------------------
+// Block traces (tools/trace_blocks.py, profiles/r03_ablation.md) show what a workgroup of the kernel above does outside its K loop:
+// ~0.8 us of setup, ~1.5-2 us until its first patch + weights have landed, 3.6-3.9 us of epilogue -- 20 % of its life at 76 x 76,
+// half of it at 304 x 304 (K = 288) -- and a CU is only at full rate while BOTH of its workgroups are inside their K loops.
+// Here the 512 (or 256) resident workgroups stay and walk tiles blockIdx, blockIdx + grid, ...: the (tile, channel slice) items
+// form ONE stream through the same LDS rings, so the patch and the first two weight tiles of the next tile are requested during the
+// last slice of the current one and are in LDS when its epilogue ends; the geometry of the next tile is computed under the K loop.
+// The epilogue's loads and stores go through buffer instructions that every wave issues unconditionally (invalid lanes carry an
+// out-of-range offset), so their number is a compile-time constant and the counted `s_waitcnt vmcnt` of the two taps that follow an
+// epilogue can leave the stores in flight.  The bias of every cout lives in LDS (the accumulators restart from it without a VMEM
+// load, which would otherwise have to wait for those stores).  fp16, whole K, OUT_NORMAL, 16-byte aligned views only.
+template <int WM, int WN, int TM, int TP, int PRG, int OCC, int MODE>
+__global__ void __launch_bounds__(512, OCC) conv3x3_tap_stream_kernel(const ConvParams p) {
+    typedef _Float16 T;
+    constexpr int NW = 8, S = 3, ROWB = 64;
+    constexpr int NA = WM * TM * 16;
+    constexpr int NB = WN * TP * 16;
+    constexpr int JA_TOT = NA / 16;
+    constexpr int JA = (JA_TOT + NW - 1) / NW;
+    constexpr int PW = 24;
+    constexpr int FROW = MODE == 2 ? PW : 16;
+    constexpr int JP = (PRG + NW - 1) / NW;
+    constexpr int CH = 4 * TM;
+    constexpr int EPC = 8;
+    constexpr int NQ = CH / EPC;                // 16-byte chunks of a lane's couts
+    constexpr int NST = TP * NQ;                // store instructions of one wave's epilogue (always issued)
+    constexpr int A_BYTES = NA * ROWB;
+    constexpr int P_BYTES = PRG * 1024;
+    constexpr int BIAS_FLOATS = kTapStreamBiasFloats;
+    static_assert(WM * WN == NW && (JA_TOT % NW == 0 || JA_TOT < NW), "tile / wave mapping");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[S * A_BYTES + 2 * P_BYTES + BIAS_FLOATS * 4];
+    unsigned char *const smemP = smem + S * A_BYTES;
+    float *const sbias = reinterpret_cast<float *>(smem + S * A_BYTES + 2 * P_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const bool has_a = JA_TOT % NW == 0 || wave < JA_TOT;   // wave-uniform
+    const int fr = lane & 15, fq = lane >> 4;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wgt), 0, p.wgt_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.res ? p.res : p.out), 0, p.res ? p.res_bytes : 0u, 0x00020000);
+
+    for (int i = tid; i < p.cout_pad && i < BIAS_FLOATS; i += 512) sbias[i] = p.bias[i];      // (read after the first tap's barrier at the earliest)
+
+    // ---- lane constants of the DMA geometry --------------------------------------------------------
+    const int lrow = lane >> 2;
+    uint32_t a_off[JA];         // without the cout tile: n0 * wrow_bytes rides in the scalar offset of the DMA
+#pragma unroll
+    for (int j = 0; j < JA; ++j) {
+        const int r = (j * NW + wave) * 16 + lrow;
+        const int ws = r / (TM * 16), R = r % (TM * 16);
+        const int tm = R >> 4, g4 = (R >> 2) & 3, jj = R & 3;
+        const int ch = ws * (TM * 16) + g4 * CH + 4 * tm + jj;
+        a_off[j] = (uint32_t)ch * p.wrow_bytes + (uint32_t)(((lane & 3) ^ tap_swz_w(lrow)) << 4);
+    }
+    constexpr int JP_FULL = PRG - (JP - 1) * NW;
+    const bool jp_full = wave < JP_FULL;
+    const uint32_t csw_p = (uint32_t)(((lane & 3) ^ (((lrow >> 2) & 1) << 1)) << 4);
+    uint32_t b_off[JP];
+    // per-tile: patch offsets of tile `bid` (remapped linear tile id) -> b_off; returns q0 and n0 of the tile
+    auto geometry = [&](int bid, int &q0, int &n0) __attribute__((always_inline)) {
+        const int mt = (int)fdiv((uint32_t)bid, p.dtiles_n);
+        n0 = (bid - mt * p.n_tiles_n) * NA;
+        q0 = mt * NB;
+        int t2_n = 0, t2_y0 = 0, t2_x0 = 0;
+        if (MODE == 2) {
+            t2_n = (int)fdiv((uint32_t)mt, p.dqHW);
+            const int r = mt - t2_n * p.qHW;
+            const int ty = (int)fdiv((uint32_t)r, p.dqW);
+            t2_y0 = ty * (NB / 16);
+            t2_x0 = (r - ty * p.qW) * 16;
+        }
+#pragma unroll
+        for (int j = 0; j < JP; ++j) {
+            const int g = j * NW + wave;
+            bool ok;
+            int n, y, x;
+            if (MODE == 2) {
+                const int R = g * 16 + lrow;
+                const int pr = R / PW, pc = R - pr * PW;
+                n = t2_n; y = t2_y0 - 1 + pr; x = t2_x0 - 1 + pc;
+                ok = g < PRG && pc < 18 && pr < NB / 16 + 2 && t2_n * p.HoWo < p.M && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+            } else {
+                const int q = q0 - (p.qW + 1) + g * 16 + lrow;
+                ok = g < PRG && q >= 0 && q < p.Mq;
+                const int qq = ok ? q : 0;
+                n = (int)fdiv((uint32_t)qq, p.dqHW);
+                const int r = qq - n * p.qHW;
+                y = (int)fdiv((uint32_t)r, p.dqW);
+                x = r - y * p.qW;
+                ok = ok && x < p.W && y < p.H;
+            }
+            const long long e = (long long)n * p.in_img_stride + ((long long)y * p.W + x) * p.in_ld + p.in_coff;
+            b_off[j] = ok ? (uint32_t)(e * 2) + csw_p : YOLO_INVALID_OFF;
+        }
+    };
+
+    const int C = p.cin_chunks >> 2;            // channel slices per tile
+    auto issue_patch = [&](int c, int buf) __attribute__((always_inline)) {
+        const uint32_t koff = (uint32_t)c * ROWB;
+#pragma unroll
+        for (int j = 0; j < JP; ++j)
+            if (j + 1 < JP || jp_full) tap_dma16(rs_in, smemP + buf * P_BYTES + (j * NW + wave) * 1024, b_off[j], koff);
+    };
+    auto issue_weights = [&](int tap, int c, int n0, int slot) __attribute__((always_inline)) {
+        const uint32_t ka = (uint32_t)(tap * p.cin_chunks + 4 * c) * 16 + (uint32_t)n0 * p.wrow_bytes;
+        if (has_a) {
+#pragma unroll
+            for (int j = 0; j < JA; ++j) tap_dma16(rs_w, smem + slot * A_BYTES + (j * NW + wave) * 1024, a_off[j], ka);
+        }
+    };
+
+    float4v acc[TM][TP];
+    const int a_frag = (wm * TM * 16 + fr) * ROWB + (((fq ^ tap_swz_w(fr)) & 3) << 4);
+    const int rb = wn * TP * FROW + fr;
+    const int c_lane = wm * (TM * 16) + fq * CH;        // first cout of this lane inside the cout tile
+    auto compute = [&](int slot, int buf, int shift) __attribute__((always_inline)) {
+        const unsigned char *A = smem + slot * A_BYTES + a_frag;
+        const int R = rb + shift;
+        const unsigned char *B = smemP + buf * P_BYTES + (R << 6) + ((fq << 4) ^ ((R & 4) << 3));
+        uint4v fa[TM], fb[TP];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const uint4v *>(A + a * 16 * ROWB);
+#pragma unroll
+        for (int b = 0; b < TP; ++b) fb[b] = *reinterpret_cast<const uint4v *>(B + b * FROW * ROWB);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TP; ++b) acc[a][b] = mma_chunk<T>(fa[a], fb[b], acc[a][b]);
+    };
+    // epilogue of one tile: leaky, + residual, fp16, 16-byte stores; NQ * TP loads (if any) and NST stores per wave, always
+    auto epilogue = [&](int q0, int n0) __attribute__((always_inline)) {
+        const int cbase = n0 + c_lane;
+        const bool c_ok = cbase < p.Cout;
+        uint32_t ooff[TP];
+        uint4v rv[TP][NQ];
+#pragma unroll
+        for (int b = 0; b < TP; ++b) {
+            int n, rem, oy, ox;
+            const bool ok = conv_decode_pixel<MODE>(p, q0 + wn * (TP * 16) + b * 16 + fr, n, rem, oy, ox) && c_ok;
+            const long long o = ((long long)n * p.out_img_stride + (long long)rem * p.out_ld + cbase) * 2;
+            ooff[b] = ok ? (uint32_t)o : YOLO_INVALID_OFF;
+            if (p.has_res) {
+                const long long ro = ((long long)n * p.res_img_stride + (long long)rem * p.res_ld + cbase) * 2;
+                const uint32_t roff = ok ? (uint32_t)ro : YOLO_INVALID_OFF;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    rv[b][q] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, q * 16, 0));
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < TP; ++b) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                T t[EPC], r[EPC];
+                if (p.has_res) __builtin_memcpy(r, &rv[b][q], 16);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const int i = q * EPC + e;
+                    float x = acc[i >> 2][b][i & 3];
+                    x = p.leaky ? fmaxf(0.1f * x, x) : x;
+                    if (p.has_res) x += (float)r[e];
+                    t[e] = (T)x;
+                }
+                uint4v u;
+                __builtin_memcpy(&u, t, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, u), rs_out, ooff[b], q * 16, 0);
+            }
+        }
+    };
+    auto init_acc = [&](int n0, bool from_lds) __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const float4v bv = from_lds ? *reinterpret_cast<const float4v *>(sbias + n0 + c_lane + 4 * a)
+                                        : *reinterpret_cast<const float4v *>(p.bias + n0 + c_lane + 4 * a);
+#pragma unroll
+            for (int b = 0; b < TP; ++b) acc[a][b] = bv;
+        }
+    };
+
+    // ---- the stream ------------------------------------------------------------------------------------
+    int it = blockIdx.x;                       // this workgroup's tiles: it, it + grid, ... (< n_blocks)
+    int q0_cur, n0_cur, q0_nxt = 0, n0_nxt = 0;
+    geometry(xcd_remap(it, p.n_blocks), q0_cur, n0_cur);
+    init_acc(n0_cur, false);
+    issue_patch(0, 0);
+    issue_weights(0, 0, n0_cur, 0);
+    issue_weights(1, 0, n0_cur, 1);
+    int c = 0;
+    bool after_epi = false;                    // the previous item ended with an epilogue: NST stores sit between its DMAs and ours
+    bool done = false;
+
+    // one (tile, slice) item; the patch buffer index is a compile-time constant
+    auto run_item = [&](auto bufc) __attribute__((always_inline)) {
+        constexpr int buf = decltype(bufc)::value;
+        const bool last_c = c + 1 == C;
+        const int it_n = last_c ? it + (int)gridDim.x : it;
+        const bool more = !last_c || it_n < p.n_blocks;
+        const int c_n = last_c ? 0 : c + 1;
+        if (!last_c) { n0_nxt = n0_cur; q0_nxt = q0_cur; }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const bool last = !more && tap == 8;
+            const bool with_patch = more && (tap == 1 || tap == 2);
+            const bool st = after_epi && tap < 2;      // the epilogue's stores are younger than the DMAs this tap waits for
+            if (last) tap_wait_vm<0>();
+            else if (has_a) {
+                if (!with_patch) { if (st) tap_wait_vm<JA + NST>(); else tap_wait_vm<JA>(); }
+                else if (jp_full) { if (st) tap_wait_vm<JA + JP + NST>(); else tap_wait_vm<JA + JP>(); }
+                else { if (st) tap_wait_vm<JA + JP - 1 + NST>(); else tap_wait_vm<JA + JP - 1>(); }
+            } else {
+                if (!with_patch) { if (st) tap_wait_vm<NST>(); else tap_wait_vm<0>(); }
+                else if (jp_full) { if (st) tap_wait_vm<JP + NST>(); else tap_wait_vm<JP>(); }
+                else { if (st) tap_wait_vm<JP - 1 + NST>(); else tap_wait_vm<JP - 1>(); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            if (tap == 0 && more) {
+                if (last_c) geometry(xcd_remap(it_n, p.n_blocks), q0_nxt, n0_nxt);      // b_off of the finished tile is dead: its last patch is in LDS
+            }
+            {   // weights two taps ahead (the stream continues into the next item)
+                if (tap + 2 < 9) issue_weights(tap + 2, c, n0_cur, (tap + 2) % S);
+                else if (more) issue_weights(tap + 2 - 9, c_n, n0_nxt, (tap + 2) % S);
+            }
+            if (tap == 0 && more) issue_patch(c_n, buf ^ 1);
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            compute(tap % S, buf, MODE == 2 ? kh * PW + kw : kh * p.qW + kw);
+        }
+        after_epi = false;
+        if (last_c) {
+            epilogue(q0_cur, n0_cur);
+            if (!more) { done = true; return; }
+            it = it_n; q0_cur = q0_nxt; n0_cur = n0_nxt;
+            init_acc(n0_cur, true);
+            after_epi = true;
+        }
+        c = c_n;
+    };
+    for (;;) {
+        run_item(std::integral_constant<int, 0>());
+        if (done) break;
+        run_item(std::integral_constant<int, 1>());
+        if (done) break;
+    }
+}
+
 // (6 = 256 couts x 224 positions, one workgroup per CU: 19 x 19 maps at batch 32 are 12 800 padded positions -> 58 x 4 = 232
 // tiles on 256 CUs, where the 256-position tiles leave 200 or 400 workgroups on 256 / 512 slots)
 // variants: 0 = 128 couts x 256 positions, 1 = 256 x 256 (one workgroup per CU), 2 = 128 x 192, 3 = 128 x 128 (smaller
@@ -343,10 +595,48 @@ const char *conv_tap_symbol(int variant, bool f32) {
     }
 }
 
+// the persistent form (conv3x3_tap_stream_kernel) is instantiated for variant 5 only (64 couts x 16 x 16 pixels, 93 VGPRs, no spill:
+// 304 x 304 32 -> 64 at batch 32 0.242 -> 0.225 ms).  The TP = 4 tiles (variants 0 and 4) sit at the 128-register limit of two
+// workgroups per CU: with the loop state of the stream they spill 19-23 VGPRs, reloads land inside the K loop (each a
+// `s_waitcnt vmcnt(0)` that drains the DMA pipeline) and the launches got 6-15 % SLOWER (profiles/r03_ablation.md) -- not built.
+#define YOLO_TAP_STREAM_VARIANTS(X) \
+    X(5, 1, 8, 4, 2, 27, 4, 2)
+
+const char *conv_tap_stream_symbol(int variant) {
+    switch (variant) {
+#define X(id, ...) case id: return "void yolo::conv3x3_tap_stream_kernel<" #__VA_ARGS__ ">(yolo::ConvParams)";
+        YOLO_TAP_STREAM_VARIANTS(X)
+#undef X
+    default: return "";
+    }
+}
+
+bool conv_tap_stream_ok(const ConvParams &p, int variant) {
+    if (variant != 5) return false;
+    if (p.f32 || p.out_f32 || p.ksplit > 1 || p.outmode != OUT_NORMAL || !p.vec_out || (p.has_res && (!p.vec_res || !p.res_bytes)) || !p.out_bytes) return false;
+    if (p.Cout % 16 || (p.Cout + 127) / 128 * 128 > kTapStreamBiasFloats) return false;
+    return true;
+}
+
+static hipError_t launch_conv_tap_stream(const ConvParams &p0, int variant, hipStream_t s) {
+    ConvParams p = p0;
+    p.cout_pad = (p.Cout + 127) / 128 * 128;
+    const int slots = 512;              // two workgroups per CU (every stream variant is OCC 4)
+    const dim3 grid((unsigned)(p.n_blocks < slots ? p.n_blocks : slots));
+    switch (variant) {
+#define X(id, ...) case id: hipLaunchKernelGGL((conv3x3_tap_stream_kernel<__VA_ARGS__>), grid, dim3(512), 0, s, p); break;
+        YOLO_TAP_STREAM_VARIANTS(X)
+#undef X
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
     if (p.ksize != 3 || p.stride != 1 || p.pad != 1 || p.Ho != p.H || p.Wo != p.W || (p.cin_chunks & 3) || !conv_tap_fits(variant, p.W) ||
         (p.f32 && !conv_tap_f32_ok(variant)))
         return hipErrorInvalidValue;
+    if (p.stream && conv_tap_stream_ok(p, variant)) return launch_conv_tap_stream(p, variant, s);
     const dim3 grid((unsigned)p.n_blocks, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
     if (p.ksplit > 1) {     // split-K instantiation (128 x 128 tile)
         if (!conv_tap_splitk_ok(variant) || !p.part || p.kunits < 1 || (long long)p.ksplit * p.kunits < (p.cin_chunks >> 2)) return hipErrorInvalidValue;

@@ -88,6 +88,7 @@ struct ConvParams {
     const void *res;           // residual tensor base (element pointer incl. coff) or null
     void *out;                 // output base pointer incl. view base / coff
     uint32_t in_bytes, wgt_bytes;
+    uint32_t out_bytes, res_bytes;     // extent of the output / residual tensors from `out` / `res` (0: beyond 2 GiB -> no buffer addressing)
     int H, W, in_ld, in_coff;
     long long in_img_stride;
     int Ho, Wo, HoWo, M;
@@ -107,6 +108,7 @@ struct ConvParams {
     // accumulators to part[s][pixel][cout_pad]; splitk_reduce_kernel (aux.hip) sums them and runs the fused epilogue
     int ksplit, kunits, cout_pad;
     float *part;
+    int stream;                // conv_tap.hip: run the persistent (stream) form where it applies
     int dbg;                   // experiment flags (YOLO_CONV_DBG): 1 skip steady-state DMA, 2 skip MFMA phase
     int qW, qHW, Mq;           // conv_tap.hip: padded-linear pixel grid, row stride W+1, image stride (H+1)(W+1), total
     int t2_shift;              // conv_tap.hip MODE 2: log2 of the positions per 2-D tile (8: 16 x 16, 7: 8 x 16)
@@ -248,6 +250,7 @@ bool dma_cfg_is_tap(int cfg);
 int dma_cfg_bkc(int cfg);
 hipError_t launch_conv_dma(const ConvParams &p, int cfg, hipStream_t s);
 hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s);       // conv_tap.hip: 3x3/1 with tap reuse
+bool conv_tap_stream_ok(const ConvParams &p, int variant);                         // the persistent form takes this launch
 bool conv_tap_fits(int variant, int W);
 bool conv_tap_is2d(int variant);
 bool conv_tap_f32_ok(int variant);            // float32 instantiation usable (tiles with room for the second accumulator)
@@ -256,6 +259,8 @@ const char *dma_cfg_name(int cfg);
 // names exactly as rocprofv3's kernel trace prints them (yolo_kernel_info.symbol: joins bench.py's roofline to profiles/*.csv)
 const char *dma_cfg_symbol(int cfg, bool f32);
 const char *conv_tap_symbol(int variant, bool f32);
+std::string dma_cfg_symbol_for(int cfg, bool f32, const ConvParams &p);      // the kernel that runs THIS launch (stream form included)
+const char *conv_tap_stream_symbol(int variant);
 std::string conv_symbol(int dtype, int cfg, bool perchunk);
 std::string first_symbol(int dtype, int cout, bool pool);
 std::string aux_symbol(int kind, int dtype, bool vec);
