@@ -243,6 +243,7 @@ bool dma_eligible(const yolo_net *net, const Kernel &k) {
 }
 // tile 0 = the 4-wave kernel of conv.hip with the planner's cfg (always available)
 bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile) {
+    if (k.outmode == OUT_POOL2 && tile != 12 && tile != 13) return false;      // the fused max-pool lives in the 16 x 16 2-D tap tiles
     if (tile == 0) return true;
     if (net->opt.dtype == YOLO_DTYPE_F32 && !dma_cfg_f32_ok(tile)) return false;
     return dma_eligible(net, k) && dma_cfg_valid(tile, k.cout, k.cpt, true, k.ksize, k.stride, k.in.W);
@@ -685,6 +686,10 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
             set_symbol(conv_symbol(net->opt.dtype, k.cfg, k.perchunk != 0));
             snprintf(out->name, sizeof out->name, "conv_igemm<%s,N%d,%s>", t, k.cfg == CFG_N128 ? 128 : k.cfg == CFG_N64 ? 64 : 32,
                      k.perchunk ? "perchunk" : "uniform");
+        }
+        if (k.outmode == OUT_POOL2) {
+            const size_t n = strlen(out->name);
+            snprintf(out->name + n, sizeof out->name - n, "+pool");
         }
         if (pk.ks > 1) {            // two launches: K splits into the float32 slab, then splitk_reduce_kernel (sum + fused epilogue)
             const size_t n = strlen(out->name);

@@ -226,6 +226,46 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, float4v (&acc
     }
 }
 
+// conv + 2x2/2 max-pool (net/layers.py:70-81 behind net/layers.py:17-67; even H and W, so the pool's zero pad row / column is never
+// read) for the 2-D tiles of conv_tap.hip (PADQ 2): fragment b of a wave is tile row (first row of the wave) + b, TP is even and
+// tiles start on even rows, so the two rows of a pool window are fragments b, b + 1 of the SAME lane and its two columns are lanes
+// fr, fr ^ 1.  Activation first (the reference pools the activated tensor), maximum in float32, one rounding, even lanes store the
+// pooled pixel (oy / 2, ox / 2) of a [Ho / 2][Wo / 2] tensor.  No residual (a conv that feeds a pool has none in this vocabulary).
+template <typename T, int TM, int TP>
+__device__ __forceinline__ void conv_epilogue_pool2(const ConvParams &p, float4v (&acc)[TM][TP], int cbase, int m_wave, int fr) {
+    constexpr int CH = 4 * TM;
+    constexpr int EPC = 16 / (int)sizeof(T);
+    static_assert(TP % 2 == 0, "pool windows pair the fragments of a wave");
+    if (cbase >= p.Cout) return;
+#pragma unroll
+    for (int b = 0; b < TP; b += 2) {
+        int n, rem, oy, ox;
+        const bool ok = conv_decode_pixel<2>(p, m_wave + b * 16 + fr, n, rem, oy, ox);       // row oy even; oy + 1 < Ho as Ho is even
+        float v[CH];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x0 = acc[a][b][j], x1 = acc[a][b + 1][j];
+                if (p.leaky) { x0 = fmaxf(0.1f * x0, x0); x1 = fmaxf(0.1f * x1, x1); }
+                const float m = fmaxf(x0, x1);
+                v[4 * a + j] = fmaxf(m, __shfl_xor(m, 1));          // lanes fr, fr ^ 1: columns ox, ox ^ 1 (same lane group fq)
+            }
+        if (!ok || (fr & 1)) continue;
+        const long long off = (long long)n * p.out_img_stride + ((long long)(oy >> 1) * (p.Wo >> 1) + (ox >> 1)) * p.out_ld + cbase;
+        T *op = reinterpret_cast<T *>(p.out);
+        T t[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) t[i] = (T)v[i];
+#pragma unroll
+        for (int i = 0; i < CH / EPC; ++i) {
+            uint4v u;
+            __builtin_memcpy(&u, t + i * EPC, 16);
+            *reinterpret_cast<uint4v *>(op + off + i * EPC) = u;
+        }
+    }
+}
+
 // Split-K: the wave's raw accumulators (no bias, no activation) go to the float32 slab part[split][pixel][cout_pad]; a lane
 // owns CH contiguous couts of a pixel -> 16-byte stores, 64 contiguous bytes per lane and fragment.
 template <int TM, int TP, int PADQ = 0>

@@ -69,6 +69,8 @@ constexpr int kTapStreamBiasFloats = 512;      // stream kernel: couts whose bia
 template <bool F32, int WM, int WN, int TM, int TP, int PRG, int OCC, int MODE, bool SPLITK>
 __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams p) {
     typedef typename std::conditional<F32, float, _Float16>::type T;
+    constexpr bool TWO_D = MODE >= 2;       // MODE 3: the 2-D tiles of MODE 2 with the max-pool behind the conv taken in the epilogue
+    constexpr int PADQ = TWO_D ? 2 : 1;
     constexpr int NW = 8;
     constexpr int S = 3;                    // weight ring slots (9 taps per slice: slot = tap % 3)
     constexpr int ROWB = 64;
@@ -79,17 +81,18 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     // MODE 2: patch row pitch in positions.  24 (a multiple of 8) keeps the swizzle phase of every fragment row equal, so the
     // fragment offsets are immediates; the three-workgroups-per-CU tile (OCC 6) takes the minimal pitch 18 to fit its two patch
     // buffers into a third of the LDS and pays one address computation per fragment and tap instead
-    constexpr int PW = (MODE == 2 && OCC >= 6) ? 18 : 24;
-    constexpr int FROW = MODE == 2 ? PW : 16;       // patch rows between consecutive fragments of a wave
+    constexpr int PW = (TWO_D && OCC >= 6) ? 18 : 24;
+    constexpr int FROW = TWO_D ? PW : 16;       // patch rows between consecutive fragments of a wave
     constexpr int JP = (PRG + NW - 1) / NW; // patch DMA wave-instructions per wave per slice
     constexpr int CH = 4 * TM;
     constexpr int A_BYTES = NA * ROWB;
     constexpr int P_BYTES = PRG * 1024;
     static_assert(WM * WN == NW, "eight waves");
     static_assert(JA_TOT % NW == 0 || JA_TOT < NW, "weight tile must split evenly over the waves (or be smaller than them)");
-    static_assert(MODE == 1 || PRG * 16 >= (NB / 16 + 2) * PW, "patch buffer too small for the 2-D tile");
+    static_assert(!TWO_D || PRG * 16 >= (NB / 16 + 2) * PW, "patch buffer too small for the 2-D tile");
     if constexpr (F32 && (TP > 2 || OCC >= 6)) return;     // never launched (launch_conv_tap refuses): no registers for the second accumulator
-    if constexpr (SPLITK && !(WM == 2 && WN == 4 && TM == 4 && TP == 2 && MODE == 1)) return;      // split-K: the 128 x 128 tile only
+    if constexpr (SPLITK && !(WM == 2 && WN == 4 && TM == 4 && TP == 2 && MODE == 1)) return;
+    if constexpr (MODE == 3 && (TP % 2 != 0 || SPLITK)) return;      // split-K: the 128 x 128 tile only
     __shared__ __attribute__((aligned(16))) unsigned char smem[S * A_BYTES + 2 * P_BYTES];
     unsigned char *const smemP = smem + S * A_BYTES;
 
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     uint32_t b_off[JP];
     const uint32_t csw_p = (uint32_t)(((lane & 3) ^ (((lrow >> 2) & 1) << 1)) << 4);
     int t2_n = 0, t2_y0 = 0, t2_x0 = 0;     // MODE 2: image and first output pixel of this block's tile
-    if (MODE == 2) {
+    if (TWO_D) {
         t2_n = (int)fdiv((uint32_t)mt, p.dqHW);             // qHW = tiles per image, qW = tiles per tile row
         const int r = mt - t2_n * p.qHW;
         const int ty = (int)fdiv((uint32_t)r, p.dqW);
@@ -142,7 +145,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         const int g = j * NW + wave;
         bool ok;
         int n, y, x;
-        if (MODE == 2) {
+        if (TWO_D) {
             const int R = g * 16 + lrow;
             const int pr = R / PW, pc = R - pr * PW;
             n = t2_n; y = t2_y0 - 1 + pr; x = t2_x0 - 1 + pc;
@@ -212,7 +215,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const uint4v *>(A + a * 16 * ROWB);
 #pragma unroll
         for (int b = 0; b < TP; ++b) {
-            if constexpr (MODE == 2 && (FROW & 7) != 0) {       // the swizzle phase differs from fragment row to fragment row
+            if constexpr (TWO_D && (FROW & 7) != 0) {       // the swizzle phase differs from fragment row to fragment row
                 const int Rb = R + b * FROW;
                 fb[b] = *reinterpret_cast<const uint4v *>(smemP + buf * P_BYTES + (Rb << 6) + ((fq << 4) ^ ((Rb & 4) << 3)));
             } else {
@@ -266,7 +269,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
             }
             if (tap == 0 && more) issue_patch(c + 1, buf ^ 1);
             const int kh = tap / 3, kw = tap - 3 * kh;
-            compute(tap % S, buf, MODE == 2 ? kh * PW + kw : kh * p.qW + kw);
+            compute(tap % S, buf, TWO_D ? kh * PW + kw : kh * p.qW + kw);
         }
     };
     for (int c = c_begin; c < C; c += 2) {
@@ -285,10 +288,12 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     const unsigned long long t_loop = p.trace ? wall_clock64() : 0ull;
 #endif
     if constexpr (SPLITK) {
-        conv_store_partial<TM, TP, MODE>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr, (int)blockIdx.y);
+        conv_store_partial<TM, TP, PADQ>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr, (int)blockIdx.y);
         return;
     } else {
-        conv_epilogue<T, TM, TP, MODE, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
+        // (a template mode, not a run-time branch: with the branch in the code the 128 x (16 x 16) tile spilled 28 VGPRs)
+        if constexpr (MODE == 3) conv_epilogue_pool2<T, TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
+        else conv_epilogue<T, TM, TP, PADQ, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
     }
 #ifdef YOLO_EXPERIMENT
     if (p.trace && tid == 0) {          // YOLO_CONV_TRACE: phase timestamps (100 MHz) + placement of wave 0 of every block
@@ -636,12 +641,21 @@ hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
     if (p.ksize != 3 || p.stride != 1 || p.pad != 1 || p.Ho != p.H || p.Wo != p.W || (p.cin_chunks & 3) || !conv_tap_fits(variant, p.W) ||
         (p.f32 && !conv_tap_f32_ok(variant)))
         return hipErrorInvalidValue;
+    if (p.outmode == OUT_POOL2 && ((variant != 4 && variant != 5) || (p.H & 1) || (p.W & 1) || p.has_res || p.ksplit > 1 || !p.vec_out || p.Cout % 16))
+        return hipErrorInvalidValue;        // the fused pool lives in the 2-D tiles' epilogue only (plan.cpp asks for it accordingly)
     if (p.stream && conv_tap_stream_ok(p, variant)) return launch_conv_tap_stream(p, variant, s);
     const dim3 grid((unsigned)p.n_blocks, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
     if (p.ksplit > 1) {     // split-K instantiation (128 x 128 tile)
         if (!conv_tap_splitk_ok(variant) || !p.part || p.kunits < 1 || (long long)p.ksplit * p.kunits < (p.cin_chunks >> 2)) return hipErrorInvalidValue;
         if (p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<true, 2, 4, 4, 2, 28, 4, 1, true>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv3x3_tap_kernel<false, 2, 4, 4, 2, 28, 4, 1, true>), grid, dim3(512), 0, s, p);
+        return hipGetLastError();
+    }
+    if (p.outmode == OUT_POOL2) {       // MODE 3 = the 2-D tile + the max-pool in the epilogue: variants 4 (fp16) and 5 (fp16, float32)
+        if (variant == 4 && !p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<false, 2, 4, 4, 4, 27, 4, 3, false>), grid, dim3(512), 0, s, p);
+        else if (variant == 5 && !p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<false, 1, 8, 4, 2, 27, 4, 3, false>), grid, dim3(512), 0, s, p);
+        else if (variant == 5) hipLaunchKernelGGL((conv3x3_tap_kernel<true, 1, 8, 4, 2, 27, 4, 3, false>), grid, dim3(512), 0, s, p);
+        else return hipErrorInvalidValue;
         return hipGetLastError();
     }
     switch (variant) {

@@ -428,6 +428,32 @@ struct Planner {
                         break;
                     }
                 }
+                // conv 3x3/1 -> max-pool 2x2/2 on a wide map: the pool is taken in the conv's epilogue (conv_common.h:
+                // conv_epilogue_pool2, 2-D tap tiles only, so the conv is pinned to one: 13 = 64 couts, 12 = 128-cout tiles) and the
+                // full-resolution tensor is never written.  Wide maps only: below ~96 columns the padded-linear tiles beat the 2-D
+                // ones by more than the pool kernel costs (r03 sweep: 52 x 52 128 -> 256 +9 us vs a 9 us pool)
+                if (!net->kernels.empty() && net->kernels.back().kind == K_CONV && net->kernels.back().layer == s &&
+                    net->kernels.back().src_layer == s && sole(s, i) && !net->opt.keep_all && d.stride == 2 && L[s].H % 2 == 0 &&
+                    L[s].W % 2 == 0 && L[s].W >= 96 && !getenv("YOLO_NO_CONV_POOL")) {
+                    Kernel &c = net->kernels.back();
+                    const bool f16 = net->opt.dtype == YOLO_DTYPE_F16;
+                    const bool tile13 = c.cout == 64, tile12 = c.cout > 64 && f16;       // (the float32 2-D tile exists for 64 couts only)
+                    if (c.ksize == 3 && c.stride == 1 && c.outmode == OUT_NORMAL && !c.has_res && !c.head && !c.stem && !has_claim[s] &&
+                        c.cpt % 4 == 0 && c.cout % 16 == 0 && (tile13 || tile12)) {
+                        View pv = out_view_for(i);
+                        if (!pv.f32 && pv.ld % epc == 0 && (pv.base + pv.coff) % epc == 0 && pv.img_stride % epc == 0) {
+                            c.outmode = OUT_POOL2;
+                            c.out = pv;
+                            c.layer = i;
+                            c.tile = tile13 ? 13 : 12;
+                            c.note += " + fused 2x2/2 max-pool (layer " + std::to_string(i) + ")";
+                            if (has_claim[i]) c.note += " -> concat slice";
+                            L[i].view = pv; L[i].materialised = true;
+                            L[s].materialised = false;
+                            break;
+                        }
+                    }
+                }
                 Kernel k;
                 k.kind = K_POOL; k.layer = i; k.in = L[s].view; k.pool_stride = d.stride;
                 if (k.in.f32) return fail(std::string(nm) + "maxpool cannot read a float32 head tensor");

@@ -17,7 +17,7 @@
 
 namespace yolo {
 
-enum OutMode { OUT_NORMAL = 0, OUT_UP2 = 1, OUT_REORG2 = 2 };
+enum OutMode { OUT_NORMAL = 0, OUT_UP2 = 1, OUT_REORG2 = 2, OUT_POOL2 = 3 };   // OUT_POOL2: the 2x2/2 max-pool behind the conv is taken in its epilogue (2-D tap tiles)
 enum BufId { BUF_NONE = -1, BUF_USER_OUT = -2, BUF_USER_IN = -3 };
 enum ConvCfg { CFG_N128 = 0, CFG_N64 = 1, CFG_N32 = 2 };   // cout-tile width of the block
 enum KernelKind { K_PREP = 0, K_CONV = 1, K_POOL = 2, K_ELTWISE = 3, K_FIRST = 4 };

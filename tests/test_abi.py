@@ -57,12 +57,14 @@ def test_plan_yolov2_and_tiny():
     net = v2.create_full_network(np.reshape(cases.COCO_V2_ANCHORS, [-1, 2]), NAMES80, False)
     p = engine.Plan(net, dtype="fp32", max_batch=16)
     assert p.weight_count == 50983561 and p.output_count == 13 * 13 * 425
-    assert p.num_kernels == 23 + 4                  # convs, pools (the first pool is taken inside the first conv); input cast, reorg and routes are free
+    assert p.num_kernels == 23 + 3                  # convs, pools (the first two pools are taken inside the convs in front of them:
+                                                    # conv_first_pool and the 208 x 208 64-cout 2-D tap tile); input cast, reorg and routes are free
+    assert engine.Plan(net, dtype="fp16", max_batch=16).num_kernels == 23 + 2      # fp16: the 104 x 104 128-cout conv takes its pool too
     d = p.describe()
     assert "fused: reorg x2" in d and d.count("concat slice") == 2
     tiny = v2.create_tiny_network(np.reshape(cases.VOC_TINY_ANCHORS, [-1, 2]), NAMES80[:20], False)
     pt = engine.Plan(tiny, dtype="fp32", max_batch=64)
-    assert pt.weight_count == 15867885 and pt.num_kernels == 9 + 5
+    assert pt.weight_count == 15867885 and pt.num_kernels == 9 + 4      # (pool 1 in conv_first, pool 3 in the 104 x 104 conv)
 
 
 def test_fallback_graph_plans():

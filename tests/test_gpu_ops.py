@@ -165,6 +165,29 @@ def test_maxpool_odd_and_same(dtype):
     check_graph(g, x, dtype, read=(2, 3))
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+def test_conv_maxpool_fused_in_2d_tap_tiles(dtype):
+    """conv 3x3/1 -> max-pool 2x2/2 on wide maps (net/v2.py:18-37 pairs): the pool is taken in the conv's epilogue (2-D tap tiles:
+    the two rows of a window are fragments of one lane, the two columns neighbouring lanes), the full-resolution tensor is never
+    written.  Partial tiles in both directions, leaky values of both signs, 64 couts (fp16 + fp32) and 128 couts (fp16 only: no
+    float32 128-cout 2-D tile, that pool stays a kernel)."""
+    g = new_graph(12, 200, 32)
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 3, 1))                  # 1
+    g.append(PL.max_pool2d(g[-1].out, 2, 2))                         # 2  fused into 1 (tile 13)
+    g.append(PL.conv2d_bn_act(g[-1].out, 128, 3, 1))                 # 3  6 x 100
+    g.append(PL.max_pool2d(g[-1].out, 2, 2))                         # 4  fused into 3 for fp16 (tile 12)
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 1, 1))                  # 5  3 x 50
+    x = synth.synthetic_input(3, 12, 200, 32, seed=17)
+    eng = check_graph(g, x, dtype, seed=6)
+    d = eng.describe()
+    assert d.count("fused 2x2/2 max-pool") == (2 if dtype == "fp16" else 1), d
+    assert eng.num_kernels == (4 if dtype == "fp16" else 5)          # prep + convs (+ the pool fp32 keeps)
+    names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
+    assert "+pool" in names, names
+    # the unfused plan (keep_all materialises every layer) gives the same values layer by layer
+    check_graph(g, x, dtype, seed=6, read=(2, 4))
+
+
 def test_variable_batch_below_max_batch():
     g = new_graph(12, 12, 3)
     g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))
