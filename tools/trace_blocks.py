@@ -60,6 +60,18 @@ for key, rec in layers.items():
     d = np.stack([t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]], 1)
     for i, nm in enumerate(["setup", "prologue+K loop", "epilogue"]):
         print("   %-16s mean %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f us" % (nm, d[:, i].mean(), *np.percentile(d[:, i], [10, 50, 90])))
+    # first round (workgroups resident from the start: two per CU) vs back-filled ones; the tail = the part of the span after the
+    # last workgroup of the first kind has finished
+    first = t[:, 0] < 2.0
+    if first.any() and (~first).any():
+        kl = t[:, 2] - t[:, 1]
+        t_first_done = np.percentile(t[first, 3], 50)
+        alone = t[:, 1] > np.percentile(t[first, 3], 90)          # started after (almost) every first-round workgroup had ended
+        print("   K loop: first round (%d wgs) mean %.2f us, back-filled (%d) mean %.2f us, started after the first round had ended (%d) mean %.2f us"
+              % (first.sum(), kl[first].mean(), (~first).sum(), kl[~first].mean(), alone.sum(), kl[alone].mean() if alone.any() else float("nan")))
+        work = kl.sum()
+        print("   sum of K-loop time %.0f us over %d CUs = %.1f us per CU at the rates measured; span %.1f us; median end of the first round %.1f us"
+              % (work, len(set(cuid)), work / len(set(cuid)) / 2.0, T if False else t[:, 3].max(), t_first_done))
     # occupancy over time
     T = t[:, 3].max()
     grid = np.linspace(0, T, int(os.environ.get("TRACE_BINS", "21")))
