@@ -8,12 +8,10 @@
 // placeholder + :17-67 conv2d_bn_act), coalesced 16-byte NHWC stores.
 // fp16 nets: input and weights are rounded to fp16 first (same operands as the MFMA path), products
 // accumulate in fp32.
-#include "yolo_internal.h"
+#include "conv_common.h"
 #include <type_traits>
 
 namespace yolo {
-
-typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 
 // POOL: the 2x2 / stride-2 max-pool that follows the first conv in Darknet-19 and tiny-YOLO (net/v2.py) is taken in
 // registers: a wave covers 32 x-positions of two adjacent rows (lane = 32 * row + x), the 2x2 window is a max over
@@ -153,6 +151,143 @@ __global__ void __launch_bounds__(256) conv_first_kernel(const FirstParams p) {
     }
 }
 
+// ---- fp16 nets, 32 couts, fused pool: the same layer on the MATRIX cores ------------------------------------------------------
+// The direct VALU kernel above runs Darknet-19's first layer + pool (416 x 416, batch 16) in 94 us = 10 % of the YOLOv2 step at
+// 0.8 TB/s: 864 FMAs per pixel make it VALU-bound.  This is the layer-1 phase of stem.hip on its own: a persistent workgroup (8 waves)
+// walks tiles of 8 x 16 POOLED outputs = 16 x 32 conv positions; the 18 x 34 x 3 float32 input patch goes, one tile ahead through
+// registers, into LDS as 8-byte fp16 pixels (R G B 0); a lane's B fragment = two whole neighbouring pixels of one patch row (two
+// ds_read_b64), K = 27 spread over two 32-deep k-steps, bias as the MFMA's C input; wave w owns pooled row w: conv rows 2w, 2w + 1 are
+// two fragments of the same lane (vertical max in registers), the columns of a window are lanes fr, fr ^ 1; leaky after the pool
+// (monotone: same value), one 16-byte store per lane (8 couts of a pooled pixel; the four lane groups make its 64 bytes).
+namespace {
+constexpr int FM_TY = 8, FM_TX = 16;                 // pooled outputs per tile
+constexpr int FM_INY = 2 * FM_TY + 2, FM_INX = 2 * FM_TX + 2;       // 18 x 34 input pixels
+constexpr int FM_PX = 36;                            // pixels per LDS patch row (34 used, index 34 only meets zero weights)
+constexpr int FM_LD = FM_PX * 4;                     // halfs per patch row
+}  // namespace
+
+__global__ void __launch_bounds__(512, 4) first_pool_mfma_kernel(const FirstParams p) {
+    typedef _Float16 T;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[FM_INY * FM_LD * 2];
+    T *const sIn = reinterpret_cast<T *>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // layer weights as MFMA A fragments (see stem.hip): tile t, row fr holds cout 8*(fr>>2) + 4t + (fr&3); k-step s, lane group fq,
+    // element j -> patch row kh = (s == 0 ? fq >> 1 : 2), pixel pw = 2 (fq & 1) + (j >> 2), channel c = j & 3
+    uint4v a1[2][2];
+    float4v bias1[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ch = 8 * (fr >> 2) + 4 * t + (fr & 3);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            T h[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kh = st == 0 ? (fq >> 1) : 2, pw = 2 * (fq & 1) + (j >> 2), c = j & 3;
+                const bool live = pw < 3 && c < 3 && (st == 0 || fq < 2);
+                const float w = p.wgt[(live ? (kh * 3 + pw) * 3 + c : 0) * 32 + ch];
+                h[j] = live ? (T)w : (T)0.f;
+            }
+            __builtin_memcpy(&a1[t][st], h, 16);
+        }
+    }
+    bias1[0] = *reinterpret_cast<const float4v *>(p.bias + 8 * fq);
+    bias1[1] = *reinterpret_cast<const float4v *>(p.bias + 8 * fq + 4);
+    for (int i = tid; i < FM_INY * FM_PX; i += 512) *reinterpret_cast<unsigned long long *>(sIn + i * 4) = 0ull;   // 4th half / spare pixels: zero for good
+    const int boff0 = (fq >> 1) * FM_LD + 2 * (fq & 1) * 4;
+    const int boff1 = (fq < 2 ? 2 : (fq >> 1)) * FM_LD + 2 * (fq & 1) * 4;
+
+    // input staging: four patch rows per pass, 128 threads per row (102 used)
+    constexpr int NIN = (FM_INY + 3) / 4;
+    float in_r[NIN];
+    const int in_col = tid & 127, in_row0 = tid >> 7;
+    const bool in_col_ok = in_col < FM_INX * 3;
+    const int in_px = in_col / 3;
+    T *const in_dst = sIn + in_row0 * FM_LD + in_px * 4 + (in_col - 3 * in_px);
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+    auto tile_origin = [&](int tile, int &n, int &py0, int &px0) {
+        const uint32_t tyx = fdiv((uint32_t)tile, p.dXB);
+        const int tx = (int)((uint32_t)tile - tyx * (uint32_t)p.xblocks);
+        n = (int)fdiv(tyx, p.dHp);
+        const int ty = (int)(tyx - (uint32_t)n * (uint32_t)p.tiles_y);
+        py0 = ty * FM_TY; px0 = tx * FM_TX;
+    };
+    auto fetch_input = [&](int tile) {
+        int n, py0, px0;
+        tile_origin(tile, n, py0, px0);
+        const float *img = p.in + (long long)n * p.H * p.W * 3;
+        const int gy0 = 2 * py0 - 1 + in_row0, gx3 = (2 * px0 - 1) * 3 + in_col;
+        const bool xok = in_col_ok && (unsigned)gx3 < (unsigned)(3 * p.W);
+        const int w3 = 3 * p.W;
+#pragma unroll
+        for (int it = 0; it < NIN; ++it) {
+            const int gy = gy0 + 4 * it;
+            const bool ok = xok && (unsigned)gy < (unsigned)p.H && (4 * it + in_row0 < FM_INY);
+            const float v = img[ok ? gy * w3 + gx3 : 0];
+            in_r[it] = ok ? v : 0.f;
+        }
+    };
+
+    int tile = blockIdx.x;
+    fetch_input(tile);
+    __syncthreads();            // the zero fill is ordered before the first tile's stores
+    for (; tile < p.n_tiles; tile += gridDim.x) {
+        int n, py0, px0;
+        tile_origin(tile, n, py0, px0);
+#pragma unroll
+        for (int it = 0; it < NIN; ++it)
+            if (in_col_ok && 4 * it + in_row0 < FM_INY) in_dst[4 * it * FM_LD] = (T)in_r[it];
+        __syncthreads();        // input patch visible
+        if (tile + (int)gridDim.x < p.n_tiles) fetch_input(tile + gridDim.x);
+        const int oy = py0 + wave;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4v m0, m1;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const T *src = sIn + (2 * wave + r) * FM_LD + (16 * half + fr) * 4;
+                typedef unsigned long long u64;
+                const u64 b00 = *reinterpret_cast<const u64 *>(src + boff0), b01 = *reinterpret_cast<const u64 *>(src + boff0 + 4);
+                const u64 b10 = *reinterpret_cast<const u64 *>(src + boff1), b11 = *reinterpret_cast<const u64 *>(src + boff1 + 4);
+                uint4v b0, b1;
+                b0.x = (unsigned)b00; b0.y = (unsigned)(b00 >> 32); b0.z = (unsigned)b01; b0.w = (unsigned)(b01 >> 32);
+                b1.x = (unsigned)b10; b1.y = (unsigned)(b10 >> 32); b1.z = (unsigned)b11; b1.w = (unsigned)(b11 >> 32);
+                float4v d0 = mma_chunk<T>(a1[0][0], b0, bias1[0]);
+                float4v d1 = mma_chunk<T>(a1[1][0], b0, bias1[1]);
+                d0 = mma_chunk<T>(a1[0][1], b1, d0);
+                d1 = mma_chunk<T>(a1[1][1], b1, d1);
+                if (r == 0) { m0 = d0; m1 = d1; }
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { m0[j] = fmaxf(m0[j], d0[j]); m1[j] = fmaxf(m1[j], d1[j]); }
+                }
+            }
+            T o[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v0 = fmaxf(m0[j], __shfl_xor(m0[j], 1)), v1 = fmaxf(m1[j], __shfl_xor(m1[j], 1));     // columns ox, ox ^ 1
+                if (p.leaky) { v0 = fmaxf(0.1f * v0, v0); v1 = fmaxf(0.1f * v1, v1); }
+                o[j] = (T)v0;
+                o[4 + j] = (T)v1;
+            }
+            const int ox = px0 + 8 * half + (fr >> 1);
+            if (!(fr & 1) && oy < Hp && ox < Wp) {
+                uint4v u;
+                __builtin_memcpy(&u, o, 16);
+                T *op = reinterpret_cast<T *>(p.out) + (long long)n * p.out_img_stride + ((long long)oy * Wp + ox) * p.out_ld + 8 * fq;
+                *reinterpret_cast<uint4v *>(op) = u;
+            }
+        }
+        __syncthreads();        // every wave has read its patch rows: the next tile may overwrite them
+    }
+}
+
+static bool first_mfma_applies(int dtype, int cout, bool pool) { return dtype == YOLO_DTYPE_F16 && cout == 32 && pool; }
+
 template <bool T, int COUT>
 static void launch_first_t(const FirstParams &p, dim3 grid, hipStream_t s) {
     if (p.pool) hipLaunchKernelGGL((conv_first_kernel<T, COUT, true>), grid, dim3(256), 0, s, p);
@@ -174,6 +309,18 @@ hipError_t launch_first(const FirstParams &p0, int dtype, hipStream_t s) {
         g = p.total / ((long long)p.H * p.W) * (p.H >> 1) * p.xblocks;
         if (g < 1 || g > 0x7fffffffLL) return hipErrorInvalidValue;
     }
+    if (first_mfma_applies(dtype, p.Cout, p.pool != 0)) {        // fp16, 32 couts, fused pool: the MFMA form
+        const int Hp = p.H >> 1, Wp = p.W >> 1;
+        p.xblocks = (Wp + FM_TX - 1) / FM_TX;
+        p.tiles_y = (Hp + FM_TY - 1) / FM_TY;
+        p.dXB = make_fastdiv((uint32_t)p.xblocks);
+        p.dHp = make_fastdiv((uint32_t)p.tiles_y);
+        const long long tiles = p.total / ((long long)p.H * p.W) * p.xblocks * p.tiles_y;
+        if (tiles < 1 || tiles > 0x7fffffffLL || (long long)p.H * p.W * 3 > 0x7fffffffLL) return hipErrorInvalidValue;
+        p.n_tiles = (int)tiles;
+        hipLaunchKernelGGL(first_pool_mfma_kernel, dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(512), 0, s, p);
+        return hipGetLastError();
+    }
     const dim3 grid((unsigned)g);
     if (dtype == YOLO_DTYPE_F16) {
         if (p.Cout == 32) launch_first_t<false, 32>(p, grid, s);
@@ -188,6 +335,7 @@ hipError_t launch_first(const FirstParams &p0, int dtype, hipStream_t s) {
 }
 
 std::string first_symbol(int dtype, int cout, bool pool) {
+    if (first_mfma_applies(dtype, cout, pool)) return "yolo::first_pool_mfma_kernel(yolo::FirstParams)";
     return std::string("void yolo::conv_first_kernel<") + (dtype == YOLO_DTYPE_F16 ? "false" : "true") + ", " + std::to_string(cout) + ", " +
            (pool ? "true" : "false") + ">(yolo::FirstParams)";
 }

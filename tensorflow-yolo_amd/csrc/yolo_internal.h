@@ -143,8 +143,9 @@ struct FirstParams {           // first layer: 3x3/1 conv on the float32 NHWC3 i
     long long total;           // B*H*W output pixels (< 2^31)
     FastDiv dW, dH, dHW;       // set by launch_first
     int pool;                  // 1: the 2x2/2 max-pool behind the conv is fused; `out` is the POOLED tensor [B,H/2,W/2,Cout]
-    int xblocks;               // pool: 128-wide x blocks per row (set by launch_first)
+    int xblocks;               // pool: 128-wide x blocks per row (set by launch_first); MFMA form: tiles per tile row
     FastDiv dXB, dHp;
+    int tiles_y, n_tiles;      // MFMA form (first_pool_mfma_kernel): 8 x 16 pooled-output tiles per image column / in all
 };
 
 struct StemParams {            // stem.hip: fused conv 3x3/1 3->32 + conv 3x3/2 32->64 (both BN + leaky), fp16 nets

@@ -188,6 +188,25 @@ def test_conv_maxpool_fused_in_2d_tap_tiles(dtype):
     check_graph(g, x, dtype, seed=6, read=(2, 4))
 
 
+@pytest.mark.parametrize("hw", [(20, 44), (32, 64), (6, 130)])
+def test_first_layer_pool_on_the_matrix_cores(hw):
+    """Darknet-19's first layer + pool in fp16 nets (conv 3x3/1 3 -> 32 + BN + leaky + 2x2/2 max-pool): first_pool_mfma_kernel
+    (8 x 16 pooled-output tiles, partial tiles in both directions, image borders = zero padding, several images) against the
+    oracle through a following conv; the float32 net keeps the direct VALU kernel (same check)"""
+    H, W = hw
+    g = new_graph(H, W, 3)
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))
+    g.append(PL.max_pool2d(g[-1].out, 2, 2))
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 3, 1))
+    x = synth.synthetic_input(3, H, W, 3, seed=23)
+    for dtype in ("fp16", "fp32"):
+        eng = check_graph(g, x, dtype, seed=2)
+        names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
+        syms = " ".join(ki.symbol.decode() for ki in eng.kernel_infos())
+        assert "conv_first_pool" in names and eng.num_kernels == 2, names
+        assert ("first_pool_mfma_kernel" in syms) == (dtype == "fp16"), syms
+
+
 def test_variable_batch_below_max_batch():
     g = new_graph(12, 12, 3)
     g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))
