@@ -25,6 +25,7 @@ static int fail(int code, const std::string &msg) {
 }
 
 namespace {
+const size_t kPairCounterBytes = 16384;            // in-launch pair split (conv_tap.hip): one int per tile, in front of the slabs
 bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile);
 size_t splitk_slab_bytes(const yolo_net *net);
 }
@@ -141,6 +142,10 @@ int yolo_net_bind_workspace(yolo_net *net, void *ws, size_t bytes) {
     if ((uintptr_t)ws % 256) return fail(YOLO_ERR_ARG, "yolo_net_bind_workspace: workspace must be 256-byte aligned");
     net->dev_ws = static_cast<unsigned char *>(ws);
     net->dev_ws_bytes = bytes;
+    if (net->splitk_bytes)      // ticket counters of the in-launch pair split (every launch returns them to zero)
+        for (int a = 0; a < net->arenas; ++a)
+            HIP_TRY(hipMemset(net->dev_ws + net->splitk_off + (size_t)a * (net->splitk_bytes / (size_t)net->arenas / 256 * 256), 0,
+                              net->splitk_bytes / (size_t)net->arenas < kPairCounterBytes ? net->splitk_bytes / (size_t)net->arenas : kPairCounterBytes));
     return YOLO_OK;
 }
 
@@ -292,7 +297,7 @@ int choose_ksplit(const Kernel &k, const ConvParams &p, int tile, size_t slab_by
 // What one conv launch runs: the tile (0 = the 4-wave kernel of conv.hip with the planner's cfg, > 0 = conv_dma.hip tile id) and
 // the K split (ks = 1: whole K).  tile_req < 0: the rules of choose_dma_cfg.  One function for the launch path, the workspace
 // sizing (split-K slab) and yolo_net_kernel_info, so what is reported is what runs.
-struct ConvPick { int tile, ks, ku; };
+struct ConvPick { int tile, ks, ku, pair; };
 const size_t kSplitkSlabMax = (size_t)64 << 20;     // per arena
 
 ConvPick pick_conv(const yolo_net *net, const Kernel &k, const ConvParams &p, int tile_req, size_t slab_bytes) {
@@ -308,7 +313,27 @@ ConvPick pick_conv(const yolo_net *net, const Kernel &k, const ConvParams &p, in
         const int ks11 = choose_ksplit(k, p, 11, slab_bytes, ku11);
         if (ks11 > 1) { tile = 11; ks = ks11; ku = ku11; }
     }
-    return ConvPick{tile, ks, ku};
+    // 129-256 tiles of 128 x 128 (13 x 13 / 19 x 19 maps at batch 8-32) with a long K: every workgroup would run ALONE on its CU at
+    // 0.6 of the rate a pair reaches (block trace, profiles/r03_ablation.md).  K in two halves inside ONE launch (conv_tap.hip):
+    // two co-resident half-K workgroups per tile, the second arriver sums -- no reduce kernel, 2 x 64 KiB of slab per tile.
+    int pair = 0;
+    if (ks <= 1 && tile > 0 && dma_cfg_is_tap(tile) && !getenv("YOLO_NO_PAIR_SPLIT")) {
+        const long long mq = (long long)(p.M / p.HoWo) * (p.H + 1) * (p.W + 1);
+        const int units = p.cin_chunks >> 2;
+        const long long ct = (p.Cout + 127) / 128;
+        // the 128 x 256 tile first (fp16): per CU the K loop of the 128 x 128 tile is bound by the LDS-DMA path (8 KiB of weights
+        // per tap for 1 MFLOP: two half-K workgroups on a CU were measured no faster than one whole-K one), the wider tile halves
+        // the weight bytes per flop
+        const long long b8 = (mq + 255) / 256 * ct, b11 = (mq + 127) / 128 * ct;
+        // (that instantiation is built for ONE workgroup per CU -- it needs 180 registers --, so at most 128 tiles = 256 half-K workgroups:
+        // 26 x 26 at batch 16 = 184 tiles ran 48 us as 368 halves against 33 us whole)
+        if (units >= 8 && !p.f32 && conv_tile_valid(net, k, 8) && b8 >= 64 && b8 <= 128 && (size_t)b8 * 2 * 131072 <= slab_bytes) {
+            tile = 8; ks = 2; ku = (units + 1) / 2; pair = 1;
+        } else if (units >= 8 && conv_tile_valid(net, k, 11) && b11 > 128 && b11 <= 256 && (size_t)b11 * 2 * 65536 <= slab_bytes) {
+            tile = 11; ks = 2; ku = (units + 1) / 2; pair = 1;
+        }
+    }
+    return ConvPick{tile, ks, ku, pair};
 }
 
 // the shape fields pick_conv reads, for a batch, without device pointers (workspace sizing, kernel_info)
@@ -342,27 +367,41 @@ size_t splitk_slab_bytes(const yolo_net *net) {
             ConvParams p;
             conv_shape_params(net, k, b, p);
             const ConvPick pk = pick_conv(net, k, p, k.tile, kSplitkSlabMax);
-            if (pk.ks > 1) {
+            if (pk.pair) {
+                const long long mq = (long long)(p.M / p.HoWo) * (p.H + 1) * (p.W + 1);
+                const int nb = dma_cfg_nb(pk.tile);
+                const size_t bytes = (size_t)((mq + nb - 1) / nb * ((p.Cout + 127) / 128)) * 2 * 128 * (size_t)nb * 4;
+                if (bytes > need) need = bytes;
+            } else if (pk.ks > 1) {
                 const size_t bytes = (size_t)pk.ks * (size_t)p.M * (size_t)((p.Cout + 127) / 128 * 128) * 4;
                 if (bytes > need) need = bytes;
             }
         }
     }
-    return (need + 4095) / 4096 * 4096;
+    // layout of an arena's slab: [ticket counters of the in-launch pair split, kPairCounterBytes | partial sums]: the counters must
+    // never be written by anything but the pair kernels (they rely on finding them at zero)
+    return need ? kPairCounterBytes + (need + 4095) / 4096 * 4096 : 0;
 }
 
 hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParams &p0, int tile_req, hipStream_t s, int arena = 0) {
     const size_t slab = net->splitk_bytes / (size_t)net->arenas / 256 * 256;      // concurrent parts (streams) must not share a slab
-    const ConvPick pk = pick_conv(net, k, p0, tile_req, slab);
+    const size_t data_bytes = slab > kPairCounterBytes ? slab - kPairCounterBytes : 0;
+    const ConvPick pk = pick_conv(net, k, p0, tile_req, data_bytes);
     const int tile = pk.tile, ks = pk.ks, ku = pk.ku;
     ConvParams p = p0;
     if (ks > 1) {
         p.ksplit = ks; p.kunits = ku;
         p.cout_pad = (p.Cout + 127) / 128 * 128;
-        p.part = reinterpret_cast<float *>(net->dev_ws + net->splitk_off + (size_t)arena * slab);
+        unsigned char *base = net->dev_ws + net->splitk_off + (size_t)arena * slab;
+        p.part = reinterpret_cast<float *>(base + kPairCounterBytes);
+        if (pk.pair) {      // counters (zeroed at bind, returned to zero by every launch) in front of the partial sums
+            p.pair = 1;
+            p.pair_cnt = reinterpret_cast<int *>(base);
+            p.part_bytes = (uint32_t)(data_bytes < 0x7ffffff0u ? data_bytes : 0x7ffffff0u);
+        }
     }
     hipError_t e = tile > 0 ? launch_conv_dma(p, tile, s) : launch_conv(p, net->opt.dtype, k.cfg, k.perchunk != 0, s);
-    if (e != hipSuccess || ks <= 1) return e;
+    if (e != hipSuccess || ks <= 1 || pk.pair) return e;
     ReduceParams r;
     memset(&r, 0, sizeof r);
     r.part = p.part; r.bias = p.bias; r.res = p.has_res ? p.res : nullptr; r.out = p.out;
@@ -669,7 +708,8 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         // which kernel runs at max_batch (bench.py runs at max_batch): the same decision the launch path takes
         ConvParams sp;
         conv_shape_params(net, k, (net->opt.max_batch + net->arenas - 1) / net->arenas, sp);
-        const ConvPick pk = pick_conv(net, k, sp, k.tile, net->splitk_bytes / (size_t)net->arenas / 256 * 256);
+        const size_t slab_i = net->splitk_bytes / (size_t)net->arenas / 256 * 256;
+        const ConvPick pk = pick_conv(net, k, sp, k.tile, slab_i > kPairCounterBytes ? slab_i - kPairCounterBytes : 0);
         const int tile = pk.tile;
         const bool f32net = net->opt.dtype == YOLO_DTYPE_F32;
         if (tile > 0) {
@@ -680,6 +720,8 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
             if (pk.ks > 1) {        // the split-K instantiation of the tap kernel (its last template argument)
                 const size_t at = sym.rfind(", false>(");
                 if (at != std::string::npos) sym.replace(at, 9, ", true>(");
+                const size_t occ = sym.find("26, 4, 1, true>(");       // the in-launch pair on the 128 x 256 tile is built for one workgroup per CU
+                if (pk.pair && occ != std::string::npos) sym.replace(occ, 16, "26, 2, 1, true>(");
             }
             set_symbol(sym);
         } else {
@@ -691,7 +733,11 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
             const size_t n = strlen(out->name);
             snprintf(out->name + n, sizeof out->name - n, "+pool");
         }
-        if (pk.ks > 1) {            // two launches: K splits into the float32 slab, then splitk_reduce_kernel (sum + fused epilogue)
+        if (pk.pair) {              // K in two halves inside the launch
+            const size_t n = strlen(out->name);
+            snprintf(out->name + n, sizeof out->name - n, "+pairK");
+            out->bytes += 2.0 * (double)li.H * li.W * ((k.cout + 127) / 128 * 128) * 4.0;
+        } else if (pk.ks > 1) {     // two launches: K splits into the float32 slab, then splitk_reduce_kernel (sum + fused epilogue)
             const size_t n = strlen(out->name);
             snprintf(out->name + n, sizeof out->name - n, "+splitK%d", pk.ks);
             out->bytes += 2.0 * pk.ks * (double)li.H * li.W * ((k.cout + 127) / 128 * 128) * 4.0;      // partial sums written + read once

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     static_assert(JA_TOT % NW == 0 || JA_TOT < NW, "weight tile must split evenly over the waves (or be smaller than them)");
     static_assert(!TWO_D || PRG * 16 >= (NB / 16 + 2) * PW, "patch buffer too small for the 2-D tile");
     if constexpr (F32 && (TP > 2 || OCC >= 6)) return;     // never launched (launch_conv_tap refuses): no registers for the second accumulator
-    if constexpr (SPLITK && !(WM == 2 && WN == 4 && TM == 4 && TP == 2 && MODE == 1)) return;
+    if constexpr (SPLITK && !(WM == 2 && WN == 4 && TM == 4 && (TP == 2 || (TP == 4 && !F32)) && MODE == 1)) return;    // split-K: the 128 x 128 tile; 128 x 256 (fp16) for the in-launch pair
     if constexpr (MODE == 3 && (TP % 2 != 0 || SPLITK)) return;      // split-K: the 128 x 128 tile only
     __shared__ __attribute__((aligned(16))) unsigned char smem[S * A_BYTES + 2 * P_BYTES];
     unsigned char *const smemP = smem + S * A_BYTES;
@@ -189,10 +189,14 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     const int fr = lane & 15, fq = lane >> 4;
     // the accumulators start from the bias (conv_common.h: conv_init_acc_bias); split-K partial sums carry none
     if constexpr (SPLITK) {
+        if ((TP != 2 || p.pair) && blockIdx.y == 0) {    // in-launch pair: the bias rides in half 0
+            conv_init_acc_bias<TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH);
+        } else {
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+            for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < TP; ++b) acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
+                for (int b = 0; b < TP; ++b) acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
+        }
     } else {
         conv_init_acc_bias<TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH);
     }
@@ -288,7 +292,53 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     const unsigned long long t_loop = p.trace ? wall_clock64() : 0ull;
 #endif
     if constexpr (SPLITK) {
-        conv_store_partial<TM, TP, PADQ>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr, (int)blockIdx.y);
+        if constexpr (TP == 2) {            // (the 128 x 256 instantiation exists for the in-launch pair only)
+            if (!p.pair) {
+                conv_store_partial<TM, TP, PADQ>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr, (int)blockIdx.y);
+                return;
+            }
+        }
+        // ---- split-K inside the launch (two halves per tile) -----------------------------------------------------------------
+        // Hand-off per cdna_hip_programming.md Guideline 16 / "In-launch split-K reduction": every wave stores its accumulators
+        // WRITE-THROUGH (sc1: no release fence), drains its own stores, the workgroup meets at a barrier, ONE lane takes the
+        // ticket (relaxed agent-scope atomic); the second arriver acquires (one agent-scope fence by that lane, drained before
+        // the barrier that releases the other waves) and reads the first arriver's slab with sc1 loads.  Placement-independent;
+        // fp32 addition commutes, so the result does not depend on which half arrives last.  The counter returns to 0.
+        constexpr uint32_t SLAB = (uint32_t)NA * NB * 4;
+        const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(p.part, 0, p.part_bytes, 0x00020000);
+        const uint32_t mine = ((uint32_t)blockIdx.x * 2u + blockIdx.y) * SLAB, other = ((uint32_t)blockIdx.x * 2u + (1u - blockIdx.y)) * SLAB;
+        typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u4;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TP; ++b)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc[a][b]), rs_part,
+                                                       mine + (uint32_t)((((wave * TM + a) * TP + b) * 64 + lane) * 16), 0, 16 /* sc1 */);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave
+        __syncthreads();                                        // ... and nobody reads the LDS rings any more
+        int *const flag = reinterpret_cast<int *>(smem);
+        if (tid == 0) {
+            const int t = __hip_atomic_fetch_add(p.pair_cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 1) {
+                __hip_atomic_store(p.pair_cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            *flag = t;
+        }
+        __syncthreads();
+        if (*flag == 0) return;             // first arriver: its half is published
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {      // TP loads in flight at a time (all TM * TP at once would need 64 more registers)
+            u4 v[TP];
+#pragma unroll
+            for (int b = 0; b < TP; ++b)
+                v[b] = __builtin_amdgcn_raw_buffer_load_b128(rs_part, other + (uint32_t)((((wave * TM + a) * TP + b) * 64 + lane) * 16), 0, 16 /* sc1 */);
+#pragma unroll
+            for (int b = 0; b < TP; ++b) acc[a][b] += __builtin_bit_cast(float4v, v[b]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        conv_epilogue<T, TM, TP, PADQ, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
         return;
     } else {
         // (a template mode, not a run-time branch: with the branch in the code the 128 x (16 x 16) tile spilled 28 VGPRs)
@@ -569,7 +619,8 @@ static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224, 128};
 static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17, 12};
 static const int kTapVariants = 8;
 static const bool kTapF32[] = {false, false, false, true, false, true, false, false};      // float32 tiles: TP <= 2 (second-level accumulator)
-bool conv_tap_splitk_ok(int variant) { return variant == 3; }      // the 128 x 128 tile has the split-K instantiation
+bool conv_tap_splitk_ok(int variant) { return variant == 3; }      // the 128 x 128 tile has the (two-pass) split-K instantiation
+bool conv_tap_pair_ok(int variant, bool f32) { return variant == 3 || (variant == 0 && !f32); }   // in-launch pair split: also the fp16 128 x 256 tile
 bool conv_tap_is2d(int variant) { return variant == 4 || variant == 5 || variant == 7; }
 bool conv_tap_f32_ok(int variant) { return variant >= 0 && variant < kTapVariants && kTapF32[variant]; }
 bool conv_tap_fits(int variant, int W) {
@@ -646,8 +697,14 @@ hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
     if (p.stream && conv_tap_stream_ok(p, variant)) return launch_conv_tap_stream(p, variant, s);
     const dim3 grid((unsigned)p.n_blocks, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
     if (p.ksplit > 1) {     // split-K instantiation (128 x 128 tile)
-        if (!conv_tap_splitk_ok(variant) || !p.part || p.kunits < 1 || (long long)p.ksplit * p.kunits < (p.cin_chunks >> 2)) return hipErrorInvalidValue;
-        if (p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<true, 2, 4, 4, 2, 28, 4, 1, true>), grid, dim3(512), 0, s, p);
+        if (!(p.pair ? conv_tap_pair_ok(variant, p.f32 != 0) : conv_tap_splitk_ok(variant)) || !p.part || p.kunits < 1 ||
+            (long long)p.ksplit * p.kunits < (p.cin_chunks >> 2))
+            return hipErrorInvalidValue;
+        if (p.pair && (p.ksplit != 2 || !p.pair_cnt || (unsigned long long)p.n_blocks * 2ull * 128ull * kTapNB[variant] * 4ull > p.part_bytes)) return hipErrorInvalidValue;
+        // (OCC 2 = up to 256 registers: the pair launches are <= 512 workgroups of half K on 256 CUs, and the 128 x 256 tile + the
+        // hand-off state spills at the 128 registers of two-per-CU residency)
+        if (variant == 0) hipLaunchKernelGGL((conv3x3_tap_kernel<false, 2, 4, 4, 4, 26, 2, 1, true>), grid, dim3(512), 0, s, p);
+        else if (p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<true, 2, 4, 4, 2, 28, 4, 1, true>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv3x3_tap_kernel<false, 2, 4, 4, 2, 28, 4, 1, true>), grid, dim3(512), 0, s, p);
         return hipGetLastError();
     }

@@ -108,6 +108,12 @@ struct ConvParams {
     // accumulators to part[s][pixel][cout_pad]; splitk_reduce_kernel (aux.hip) sums them and runs the fused epilogue
     int ksplit, kunits, cout_pad;
     float *part;
+    // split-K IN the launch (conv_tap.hip, 128 x 128 tile, ksplit == 2): both halves of a tile write their accumulators to
+    // part[tile][half] (write-through), take a ticket from pair_cnt[tile], and the second arriver adds the other half and runs
+    // the fused epilogue -- no reduce launch.  For launches of 129-256 tiles (13 x 13 / 19 x 19 maps at batch 8-32).
+    int pair;
+    int *pair_cnt;
+    uint32_t part_bytes;
     int stream;                // conv_tap.hip: run the persistent (stream) form where it applies
     int dbg;                   // experiment flags (YOLO_CONV_DBG): 1 skip steady-state DMA, 2 skip MFMA phase
     int qW, qHW, Mq;           // conv_tap.hip: padded-linear pixel grid, row stride W+1, image stride (H+1)(W+1), total
@@ -271,6 +277,7 @@ int dma_cfg_nb(int cfg);
 bool dma_cfg_splitk_ok(int cfg);        // the kernel behind this tile id takes ConvParams.ksplit
 hipError_t launch_splitk_reduce(const ReduceParams &p, hipStream_t s);
 bool conv_tap_splitk_ok(int variant);
+bool conv_tap_pair_ok(int variant, bool f32);
 hipError_t launch_prep(const PrepParams &p, int dtype, hipStream_t s);
 hipError_t launch_resize(const ResizeParams &p, hipStream_t s);
 hipError_t launch_first(const FirstParams &p, int dtype, hipStream_t s);
