@@ -32,6 +32,10 @@ CASES = {
                          cls_boost=0.0, threshold=0.5, iou=0.6, anchors=COCO_V3_ANCHORS, ties=0),
     "v3_320_lowthr": dict(version=3, input=320, batch=1, classes=80, seed=24, scale=2.0, obj_shift=-3.0,
                           cls_boost=0.0, threshold=0.25, iou=0.45, anchors=COCO_V3_ANCHORS, ties=4),
+    # the headline size WITH suppression work (v3_608 above keeps all of its 141 candidates): box logits scaled down
+    # so that boxes are anchor-sized around their cell centres and neighbouring cells / anchors overlap
+    "v3_608_dense": dict(version=3, input=608, batch=1, classes=80, seed=25, scale=2.0, obj_shift=-3.9,
+                         cls_boost=0.0, threshold=0.5, iou=0.3, anchors=COCO_V3_ANCHORS, ties=3, box_scale=0.1),
 }
 
 
@@ -51,6 +55,8 @@ def make_head(case):
     rows, width = head_rows(c)
     t = (rng.randn(c["batch"], rows, width) * c["scale"]).astype(np.float32)
     t[..., 4] += np.float32(c["obj_shift"])
+    if c.get("box_scale"):
+        t[..., 0:4] *= np.float32(c["box_scale"])
     if c["cls_boost"]:
         hot = rng.randint(0, c["classes"], size=(c["batch"], rows))
         bi, ri = np.meshgrid(np.arange(c["batch"]), np.arange(rows), indexing="ij")

@@ -317,7 +317,8 @@ ConvPick pick_conv(const yolo_net *net, const Kernel &k, const ConvParams &p, in
     // 0.6 of the rate a pair reaches (block trace, profiles/r03_ablation.md).  K in two halves inside ONE launch (conv_tap.hip):
     // two co-resident half-K workgroups per tile, the second arriver sums -- no reduce kernel, 2 x 64 KiB of slab per tile.
     int pair = 0;
-    if (ks <= 1 && tile > 0 && dma_cfg_is_tap(tile) && !getenv("YOLO_NO_PAIR_SPLIT")) {
+    static const bool no_pair = getenv("YOLO_NO_PAIR_SPLIT") != nullptr;       // A/B switch (read once; results unchanged up to summation order)
+    if (ks <= 1 && tile > 0 && dma_cfg_is_tap(tile) && !no_pair) {
         const long long mq = (long long)(p.M / p.HoWo) * (p.H + 1) * (p.W + 1);
         const int units = p.cin_chunks >> 2;
         const long long ct = (p.Cout + 127) / 128;
