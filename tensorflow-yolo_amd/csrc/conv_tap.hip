@@ -494,30 +494,36 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_stream_kernel(const Conv
     };
     // epilogue of one tile: leaky, + residual, fp16, 16-byte stores; NQ * TP loads (if any) and NST stores per wave, always
     auto epilogue = [&](int q0, int n0) __attribute__((always_inline)) {
+        // the residual of DEPTH fragments is in flight at a time: all of them for the TP = 2 tile; two for the TP = 4 tiles, whose 128
+        // registers cannot hold 32 residual registers next to the K loop's state that has to survive the epilogue here
+        constexpr int DEPTH = TP > 2 ? 2 : TP;
         const int cbase = n0 + c_lane;
         const bool c_ok = cbase < p.Cout;
-        uint32_t ooff[TP];
-        uint4v rv[TP][NQ];
-#pragma unroll
-        for (int b = 0; b < TP; ++b) {
+        uint32_t ooff[DEPTH];
+        uint4v rv[DEPTH][NQ];
+        auto request = [&](int b, int slot) __attribute__((always_inline)) {
             int n, rem, oy, ox;
             const bool ok = conv_decode_pixel<MODE>(p, q0 + wn * (TP * 16) + b * 16 + fr, n, rem, oy, ox) && c_ok;
             const long long o = ((long long)n * p.out_img_stride + (long long)rem * p.out_ld + cbase) * 2;
-            ooff[b] = ok ? (uint32_t)o : YOLO_INVALID_OFF;
+            ooff[slot] = ok ? (uint32_t)o : YOLO_INVALID_OFF;
             if (p.has_res) {
                 const long long ro = ((long long)n * p.res_img_stride + (long long)rem * p.res_ld + cbase) * 2;
                 const uint32_t roff = ok ? (uint32_t)ro : YOLO_INVALID_OFF;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
-                    rv[b][q] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, q * 16, 0));
+                    rv[slot][q] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, q * 16, 0));
             }
-        }
+        };
+#pragma unroll
+        for (int b = 0; b < DEPTH; ++b) request(b, b);
 #pragma unroll
         for (int b = 0; b < TP; ++b) {
+            constexpr int dummy = 0; (void)dummy;
+            const int slot = b % DEPTH;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 T t[EPC], r[EPC];
-                if (p.has_res) __builtin_memcpy(r, &rv[b][q], 16);
+                if (p.has_res) __builtin_memcpy(r, &rv[slot][q], 16);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const int i = q * EPC + e;
@@ -528,7 +534,11 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_stream_kernel(const Conv
                 }
                 uint4v u;
                 __builtin_memcpy(&u, t, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, u), rs_out, ooff[b], q * 16, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, u), rs_out, ooff[slot], q * 16, 0);
+            }
+            if (b + DEPTH < TP) {
+                __builtin_amdgcn_sched_barrier(0);      // (keeps the next request behind this fragment's use of the slot)
+                request(b + DEPTH, slot);
             }
         }
     };
@@ -653,8 +663,9 @@ const char *conv_tap_symbol(int variant, bool f32) {
 
 // the persistent form (conv3x3_tap_stream_kernel) is instantiated for variant 5 only (64 couts x 16 x 16 pixels, 93 VGPRs, no spill:
 // 304 x 304 32 -> 64 at batch 32 0.242 -> 0.225 ms).  The TP = 4 tiles (variants 0 and 4) sit at the 128-register limit of two
-// workgroups per CU: with the loop state of the stream they spill 19-23 VGPRs, reloads land inside the K loop (each a
-// `s_waitcnt vmcnt(0)` that drains the DMA pipeline) and the launches got 6-15 % SLOWER (profiles/r03_ablation.md) -- not built.
+// workgroups per CU: with the loop state of the stream they spill (19-23 VGPRs with all four residual fragments in flight, 5-17 with
+// the two-deep residual pipeline the epilogue has for them), reloads land inside the K loop (each a `s_waitcnt vmcnt(0)` that drains
+// the DMA pipeline) and the launches got SLOWER both times: 76 x 76 +15 % / +3 %, 152 x 152 +6.5 % / +13 % (profiles/r03_ablation.md).
 #define YOLO_TAP_STREAM_VARIANTS(X) \
     X(5, 1, 8, 4, 2, 27, 4, 2)
 
