@@ -518,7 +518,6 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_stream_kernel(const Conv
         for (int b = 0; b < DEPTH; ++b) request(b, b);
 #pragma unroll
         for (int b = 0; b < TP; ++b) {
-            constexpr int dummy = 0; (void)dummy;
             const int slot = b % DEPTH;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
