@@ -66,6 +66,32 @@ def make_model(kind, size, batch, dtype, seed=0, streams=0, max_boxes=256, **eng
     return model, w, anchors, ncls
 
 
+def two_stream_leg(kind, size, batch, dtype, w, xs, args):
+    """The same K steps with the batch run as two independent halves on two HIP streams (yolo_net_options.streams = 2,
+    DESIGN.md "Kernel boundaries"): the kernels' tails and launch boundaries of one half overlap the other half's kernels.
+    Reported BESIDE `value` (which stays the one-stream number the per-launch `roofline` figures belong to)."""
+    import torch
+    from tensorflow_yolo_amd import YoloV2, YoloV2Tiny, YoloV3
+    from tensorflow_yolo_amd.net import dist as ydist
+    cls, anchors, ncls = {"v3": (YoloV3, COCO_V3, 80), "v2": (YoloV2, COCO_V2, 80), "v2-tiny": (YoloV2Tiny, VOC_TINY, 20)}[kind]
+    model = cls()
+    model.build(anchors, ["c%d" % i for i in range(ncls)], (size, size, 3), dtype=dtype, max_batch=batch, weights=w, streams=2,
+                max_boxes=args.max_boxes)
+    eng = model.net.engine
+    for i in range(args.warmup):
+        ydist.detect_sharded(eng, xs[i & 1], args.threshold, args.iou_threshold)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        _, _, status = ydist.detect_sharded(eng, xs[i & 1], args.threshold, args.iou_threshold)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if status.cpu().numpy().any():
+        raise RuntimeError("two-stream leg: record capacity exceeded")
+    return {"streams": 2, "value": round(args.steps * batch / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "note": "same build, same inputs and K steps, batch as two halves on two HIP streams (opt-in mode; `value` is the one-stream run)"}
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -166,6 +192,7 @@ def main():
     ap.add_argument("--autotune", action="store_true", help="time every conv tile per layer on the device first (default: built-in rules)")
     ap.add_argument("--streams", type=int, default=0, help="run every batch as this many independent parts on as many HIP streams "
                     "(overlaps the kernels' tails; the per-kernel roofline figures then describe one part's launches run alone)")
+    ap.add_argument("--no-two-stream-leg", action="store_true", help="skip the extra timed leg with --streams 2 (N = 1 only)")
     ap.add_argument("--threshold", type=float, default=0.5)
     ap.add_argument("--iou-threshold", type=float, default=0.6)
     ap.add_argument("--dump-kernels", default=None, help="write the per-kernel timing table (JSON) here")
@@ -292,6 +319,8 @@ def main():
             "roofline": roof,
             "forward_frac_of_mfma_peak": round(eng.flops_per_image * total_images / elapsed / 1e12 / (PEAK[dtype] * world), 4),
         }
+        if world == 1 and args.streams == 0 and batch >= 2 and not args.no_two_stream_leg:
+            out["two_streams"] = two_stream_leg(kind, size, batch, dtype, w, xs, args)
         out["cpu_baseline"] = out["parity"] = None
         # the CPU baseline is timed on rank 0 at N = 1 only (bench contract); the parity check (rank 0's engine, two images,
         # outside the timed region, before the process group goes away) runs at every N
