@@ -328,6 +328,18 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
     if (!tap_only && taps == 9 && stride == 1 && W > 110 && cout <= 128 && cin_chunks <= 8 && M >= 262144 &&
         dma_cfg_valid(12, cout, cin_chunks, v1_ok, ksize, stride, W))
         return 12;
+    // ... and at a quarter of that batch the 8 x 16 tile at three workgroups per CU (152x152 64->128 at batch 8: 40 us vs 47.5 on
+    // the per-tap LDS-DMA tile the model picks; at batch 32 it is the slower of the two 2-D tiles, 161 vs 155)
+    if (!tap_only && taps == 9 && stride == 1 && W > 110 && cout <= 128 && cin_chunks <= 8 && M >= 65536 && M < 262144 &&
+        dma_cfg_valid(16, cout, cin_chunks, v1_ok, ksize, stride, W))
+        return 16;
+    // float32, MFMA-bound (fp32 matrix peak is 1/16 of fp16's): long K on a 13x13 map over more than one round of workgroups.  There
+    // the padded-linear grid's (14/13)^2 = 16 % of computed-and-dropped positions are the whole difference: tiny-YOLOv2 b64
+    // 1024->1024 2.09 ms on the tap tile (97 TFLOP/s) vs 1.81 ms on the 4-wave kernel (113 TFLOP/s = 72 % of the fp32 MFMA peak),
+    // 512->1024 1.06 vs 0.91 ms; 256->512 (one round, K 2304) and every 26x26 / 52x52 layer stay faster on the tap tile.
+    if (tap_only && v1_ok && taps == 9 && stride == 1 && W <= 14 && taps * cin_chunks * 4 >= 4608 &&
+        ((long long)M * (W + 1) * (W + 1) / ((long long)W * W) + 127) / 128 * ((cout + 127) / 128) > 512)
+        return 0;
     const double k64 = taps * cin_chunks / 8.0;         // 64-deep K tiles
     int best = fallback;
     double best_t = 1e300;
@@ -336,7 +348,9 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
         // layer measured (tiny-YOLOv2 b64: 1024->1024 at 13x13 2.26 -> 2.06 ms), so the 4-wave kernel is only the fallback
         if (tap_only && !dma_cfg_f32_ok(c)) continue;
         if (c == 12 && W <= 110) continue;      // the padded-linear tiles fit and measured faster (104x104: 70 vs 84 us)
-        if (c == 14 && taps != 1) continue;     // measured 10-20 % slower than the larger tiles on every 3x3 layer
+        // the three-per-CU tile: 1x1 layers; measured 10-20 % slower than the larger tiles on every 3x3 layer that fills the chip, but
+        // the best LDS-DMA tile for a stride-2 layer of <= 256 workgroups (19x19 512->1024 at batch 8: 57 us vs 72 on the 4-wave kernel)
+        if (c == 14 && taps != 1 && !(stride == 2 && (long long)((M + 127) / 128) * ((cout + 127) / 128) <= 256)) continue;
         if (c == 7 || c == 13 || c == 16 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
         const DmaCfg &k = kCfgs[c];
         // tap-reuse tiles walk the padded position grid: (H+1)(W+1) positions per image (square maps assumed here)
