@@ -349,8 +349,10 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
         if (tap_only && !dma_cfg_f32_ok(c)) continue;
         if (c == 12 && W <= 110) continue;      // the padded-linear tiles fit and measured faster (104x104: 70 vs 84 us)
         // the three-per-CU tile: 1x1 layers; measured 10-20 % slower than the larger tiles on every 3x3 layer that fills the chip, but
-        // the best LDS-DMA tile for a stride-2 layer of <= 256 workgroups (19x19 512->1024 at batch 8: 57 us vs 72 on the 4-wave kernel)
-        if (c == 14 && taps != 1 && !(stride == 2 && (long long)((M + 127) / 128) * ((cout + 127) / 128) <= 256)) continue;
+        // the best tile for a stride-2 layer of 129-256 workgroups (19x19 512->1024 at batch 8: 57 us vs 72 on the 4-wave kernel)
+        // (with <= 128 workgroups the 4-wave kernel's split-K wins: 25 vs 49 us at batch 1)
+        const long long wg128 = (long long)((M + 127) / 128) * ((cout + 127) / 128);
+        if (c == 14 && taps != 1 && !(stride == 2 && wg128 > 128 && wg128 <= 256)) continue;
         if (c == 7 || c == 13 || c == 16 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
         const DmaCfg &k = kCfgs[c];
         // tap-reuse tiles walk the padded position grid: (H+1)(W+1) positions per image (square maps assumed here)
