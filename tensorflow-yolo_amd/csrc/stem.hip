@@ -13,8 +13,11 @@
 //            k-steps so that a lane's 8 k are two WHOLE neighbouring pixels of one patch row = 16 contiguous bytes
 //            (two ds_read_b64; the 2-byte gather of round 1/2 cost 8 conflicting ds_read_u16 + packing per lane:
 //            SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.32), bias as the MFMA's C input, leaky, ZERO outside the image (= layer 2's
-//            padding), fp16, written as 64-byte rows of an LDS patch whose columns are de-interleaved by parity, so
-//            that the stride-2 taps of 16 consecutive outputs read 16 consecutive rows;
+//            padding), fp16, written as 64-byte rows of an LDS patch whose columns are de-interleaved by parity (all
+//            even-column positions, then all odd-column ones), so that the stride-2 taps of 16 consecutive outputs read
+//            16 consecutive rows; a group of 16 layer-1 positions has ONE column parity, so it also WRITES 16 consecutive
+//            rows (round 3: with the row-pair swizzle both directions are bank-conflict-free; rounds 1-2 wrote rows
+//            alternating between the two parity blocks, 3.5 LDS cycles per 8-lane store group instead of 1);
 //   phase 2  layer 2: 9 taps x one k-step, A = weight tile of the tap, B = patch rows (shift-invariant swizzle of
 //            conv_tap.hip), bias + leaky, 32-byte NHWC stores (a lane owns 16 contiguous couts);
 //   phase 3  (when the planner hands it over) the 1x1 64->32 conv + BN + leaky that follows in Darknet-53, straight
@@ -37,20 +40,27 @@ __device__ __forceinline__ void stem_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned
 }
 
 __device__ __forceinline__ int stem_swz_w(int r) { return (0x78 >> (2 * ((r >> 2) & 3))) & 3; }   // weight rows: {0,2,3,1}[(r>>2)&3]
-__device__ __forceinline__ int stem_swz_p(int r) { return ((r >> 2) & 1) << 1; }                  // patch rows: any row shift
+// patch rows: row mod 8 -> (row & 1, chunk) is a bijection, so the eight consecutive rows one ds_write_b128 lane group stores cover all 32
+// banks once, and ds_read_b128 of 16 consecutive rows stays conflict-free under ANY row shift (the four rows of a residue class mod 4 in
+// one hardware lane group are fq = 0, 1, 1, 0 with (row >> 2) = u .. u + 3: chunks {b, 3 ^ b, 1 ^ b, 2 ^ b} for b = (row >> 1) & 1)
+__device__ __forceinline__ int stem_swz_p(int r) { return (r >> 1) & 3; }
 
 constexpr int TY = 8, TX = 16;              // layer-2 outputs per workgroup
 constexpr int P1Y = 2 * TY + 1;             // 17 layer-1 rows
 constexpr int P1X = 2 * TX + 1;             // 33 layer-1 columns
-constexpr int NPOS = P1Y * P1X;             // 561 layer-1 positions
-constexpr int NGRP = (NPOS + 15) / 16;      // 36 groups of 16 positions
+constexpr int EVEN_COLS = (P1X + 1) / 2;    // 17 even columns per layer-1 row
+constexpr int ODD_COLS = P1X / 2;           // 16 odd ones
+constexpr int NEVEN = P1Y * EVEN_COLS;      // 289 even-column positions: patch rows 0..288, [py][i] with pitch 17
+constexpr int GEVEN = (NEVEN + 15) / 16;    // 19 groups of 16 of them
+constexpr int ODD0 = GEVEN * 16;            // odd-column positions: patch rows 304.., [py][i] with pitch 16 (one group = one layer-1 row)
+constexpr int NGRP = GEVEN + P1Y;           // 36 groups of 16 positions
 constexpr int INY = P1Y + 2, INX = P1X + 2; // 19 x 35 input pixels
 constexpr int IN_PX = 36;                   // pixels per input patch row (35 used + one that only zero weights meet)
-constexpr int IN_LD = IN_PX * 4;            // halfs per input patch row: a pixel is R G B 0 = 8 bytes
-constexpr int EVEN_COLS = (P1X + 1) / 2;    // 17 even columns come first in a patch row block
+constexpr int IN_SKEW_PX = 32;              // pixels >= 32 sit 8 bytes further: a lane group's 17 pixel pairs then never share a bank
+constexpr int IN_LD = IN_PX * 4 + 4;        // halfs per input patch row: a pixel is R G B 0 = 8 bytes (+ the skew slot)
 constexpr int W2_BYTES = 9 * 64 * 64;
 constexpr int P_BYTES = NGRP * 16 * 64;
-constexpr int IN_BYTES = INY * IN_LD * 2;
+constexpr int IN_BYTES = (INY * IN_LD * 2 + 15) / 16 * 16;     // (the bias table behind it is read 16 bytes at a time)
 constexpr int BIAS_BYTES = (64 + 32) * 4;  // layer-2 and layer-3 biases (read per tile: keeps 24 VGPRs free)
 
 }  // namespace
@@ -107,13 +117,14 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
         bias1[1] = *reinterpret_cast<const float4v *>(p.b1 + 8 * fq + 4);
         if (tid < 64) sBias[tid] = p.b2[tid];
         else if (tid < 96 && p.w3) sBias[tid] = p.b3[tid - 64];
-        // the fourth half of every pixel and the 36th pixel of every row are never written again: zero (finite) for good
-        for (int i = tid; i < INY * IN_PX; i += 512) *reinterpret_cast<unsigned long long *>(sIn + i * 4) = 0ull;
+        // the fourth half of every pixel, the 36th pixel and the skew slot of every row are never written again: zero (finite) for good
+        for (int i = tid; i < INY * (IN_LD / 4); i += 512) *reinterpret_cast<unsigned long long *>(sIn + i * 4) = 0ull;
     }
-    // per-lane patch offsets (halfs) of the two B fragments: step 0 row fq >> 1, step 1 row 2 (lane groups 2, 3 meet zero
-    // weights there and re-read rows 0 / 1: finite values)
-    const int boff0 = (fq >> 1) * IN_LD + 2 * (fq & 1) * 4;
-    const int boff1 = (fq < 2 ? 2 : (fq >> 1)) * IN_LD + 2 * (fq & 1) * 4;
+    // per-lane patch rows of the two B fragments: step 0 row fq >> 1, step 1 row 2 (lane groups 2, 3 meet zero weights there and
+    // re-read row 1: finite values); the lane's two pixels are px + 2 (fq & 1) and the next one
+    const int brow0 = (fq >> 1) * IN_LD;
+    const int brow1 = (fq < 2 ? 2 : (fq >> 1)) * IN_LD;
+    auto in_pix = [](int px) { return px * 4 + (px >= IN_SKEW_PX ? 4 : 0); };      // halfs
     const int a_frag = fr * 64 + (((fq ^ stem_swz_w(fr)) & 3) << 4);
     // optional layer 3 (1x1 64->32): the lane already owns 16 channels of its pixel after layer 2, and an MFMA sums over
     // k in any order, so k-step ks takes channels 16 fq + 8 ks + j straight from the lane's registers (no LDS round
@@ -137,7 +148,7 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
     const int in_col = tid & 127, in_row0 = tid >> 7;
     const bool in_col_ok = in_col < INX * 3;
     const int in_px = in_col / 3;
-    T *const in_dst = sIn + in_row0 * IN_LD + in_px * 4 + (in_col - 3 * in_px);
+    T *const in_dst = sIn + in_row0 * IN_LD + in_pix(in_px) + (in_col - 3 * in_px);
     auto tile_origin = [&](int tile, int &n, int &oy0, int &ox0) {
         const uint32_t tyx = fdiv((uint32_t)tile, p.dtx);
         const int tx = (int)((uint32_t)tile - tyx * (uint32_t)p.tiles_x);
@@ -177,15 +188,25 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
         if (tile + (int)gridDim.x < p.n_tiles) fetch_input(tile + gridDim.x);
 
         // ---- phase 1: layer 1 for the 17 x 33 positions --------------------------------------------
+        // A group of 16 positions has ONE column parity (groups 0..18: the 289 even-column positions, 19..35: one row of 16 odd columns
+        // each), so its 16 lanes store 16 CONSECUTIVE rows of the de-interleaved patch: rowP = 16 g + fr.
         for (int g = wave; g < NGRP; g += 8) {
-            const int pp = g * 16 + fr;
-            const bool live = pp < NPOS;
-            const int pc = live ? pp : NPOS - 1;
-            const int py = pc / P1X, px = pc - py * P1X;
-            const T *src = sIn + py * IN_LD + px * 4;
+            const int rowP = g * 16 + fr;
+            const bool live = g >= GEVEN || rowP < NEVEN;
+            int py, px;
+            if (g < GEVEN) {            // (wave-uniform)
+                const int e = live ? rowP : NEVEN - 1;
+                py = e / EVEN_COLS;
+                px = 2 * (e - py * EVEN_COLS);
+            } else {
+                py = g - GEVEN;
+                px = 2 * fr + 1;
+            }
+            const T *src = sIn + py * IN_LD;
+            const int q0 = in_pix(px + 2 * (fq & 1)), q1 = in_pix(px + 2 * (fq & 1) + 1);
             typedef unsigned long long u64;
-            const u64 b00 = *reinterpret_cast<const u64 *>(src + boff0), b01 = *reinterpret_cast<const u64 *>(src + boff0 + 4);
-            const u64 b10 = *reinterpret_cast<const u64 *>(src + boff1), b11 = *reinterpret_cast<const u64 *>(src + boff1 + 4);
+            const u64 b00 = *reinterpret_cast<const u64 *>(src + brow0 + q0), b01 = *reinterpret_cast<const u64 *>(src + brow0 + q1);
+            const u64 b10 = *reinterpret_cast<const u64 *>(src + brow1 + q0), b11 = *reinterpret_cast<const u64 *>(src + brow1 + q1);
             uint4v b0, b1;
             b0.x = (unsigned)b00; b0.y = (unsigned)(b00 >> 32); b0.z = (unsigned)b01; b0.w = (unsigned)(b01 >> 32);
             b1.x = (unsigned)b10; b1.y = (unsigned)(b10 >> 32); b1.z = (unsigned)b11; b1.w = (unsigned)(b11 >> 32);
@@ -206,7 +227,6 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
             uint4v u;
             __builtin_memcpy(&u, o, 16);
             if (!inside) u = uint4v{0u, 0u, 0u, 0u};        // layer 2's zero padding (tiles on the image border only)
-            const int rowP = py * P1X + ((px & 1) ? EVEN_COLS + (px >> 1) : (px >> 1));
             if (live) *reinterpret_cast<uint4v *>(sP + rowP * 64 + ((fq ^ stem_swz_p(rowP)) << 4)) = u;
         }
         __syncthreads();    // patch P complete; the input patch may be overwritten
@@ -220,7 +240,7 @@ __global__ void __launch_bounds__(512, 4) stem_v3_kernel(const StemParams p) {
             uint4v fb[3];
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
-                const int rowP = (2 * wave + kh) * P1X + (kw & 1) * EVEN_COLS + fr + (kw >> 1);
+                const int rowP = (kw & 1) ? ODD0 + (2 * wave + kh) * ODD_COLS + fr : (2 * wave + kh) * EVEN_COLS + fr + (kw >> 1);
                 fb[kw] = *reinterpret_cast<const uint4v *>(sP + rowP * 64 + ((fq ^ stem_swz_p(rowP)) << 4));
             }
 #pragma unroll
