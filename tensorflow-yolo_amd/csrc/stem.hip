@@ -61,6 +61,9 @@ constexpr int IN_LD = IN_PX * 4 + 4;        // halfs per input patch row: a pixe
 constexpr int W2_BYTES = 9 * 64 * 64;
 constexpr int P_BYTES = NGRP * 16 * 64;
 constexpr int IN_BYTES = (INY * IN_LD * 2 + 15) / 16 * 16;     // (the bias table behind it is read 16 bytes at a time)
+static_assert((W2_BYTES + P_BYTES + IN_BYTES) % 16 == 0 && (W2_BYTES + P_BYTES) % 16 == 0 && (IN_LD * 2) % 8 == 0,
+              "LDS regions read with ds_read_b128 / b64 keep their alignment (a misaligned bias table cost 27 % of the kernel: SQ_LDS_UNALIGNED_STALL)");
+static_assert(ODD0 + P1Y * ODD_COLS <= NGRP * 16 && 2 * (W2_BYTES + P_BYTES + IN_BYTES + (64 + 32) * 4) <= 160 * 1024, "patch rows / two workgroups per CU");
 constexpr int BIAS_BYTES = (64 + 32) * 4;  // layer-2 and layer-3 biases (read per tile: keeps 24 VGPRs free)
 
 }  // namespace
