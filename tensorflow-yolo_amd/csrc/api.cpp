@@ -248,7 +248,7 @@ bool dma_eligible(const yolo_net *net, const Kernel &k) {
 }
 // tile 0 = the 4-wave kernel of conv.hip with the planner's cfg (always available)
 bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile) {
-    if (k.outmode == OUT_POOL2 && tile != 12 && tile != 13) return false;      // the fused max-pool lives in the 16 x 16 2-D tap tiles
+    if (k.outmode == OUT_POOL2 && tile != 12 && tile != 13 && tile != 17) return false;      // the fused max-pool lives in the 16 x 16 2-D tap tiles
     if (tile == 0) return true;
     if (net->opt.dtype == YOLO_DTYPE_F32 && !dma_cfg_f32_ok(tile)) return false;
     return dma_eligible(net, k) && dma_cfg_valid(tile, k.cout, k.cpt, true, k.ksize, k.stride, k.in.W);

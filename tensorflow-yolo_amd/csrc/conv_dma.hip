@@ -260,11 +260,12 @@ static const DmaCfg kCfgs[] = {
     {128, 128, 3, 1.00f, "128x128,K32,S3,x3", 4},      // 14: conv_dma again: 48 KiB LDS, <= 80 VGPRs: three workgroups per CU (short-K 1x1 layers)
     {256, 224, 1, 1.00f, "256x224,tap9", 4},           // 15: conv_tap.hip variant 6 (see there)
     {128, 128, 3, 1.00f, "128x128,tap9,2d,x3", 4},     // 16: conv_tap.hip variant 7: 8 x 16 2-D tile, three workgroups per CU
+    {32, 256, 2, 1.00f, "32x256,tap9,2d,x2", 4},       // 17: conv_tap.hip variant 8: 32 couts x (16 x 16)
 };
-static const int kNumCfgs = 17;
+static const int kNumCfgs = 18;
 static const int kFirstTapCfg = 8, kLastTapCfg = 13;
-static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || cfg == 15 || cfg == 16; }
-static inline int tap_variant(int cfg) { return cfg == 15 ? 6 : cfg == 16 ? 7 : cfg - kFirstTapCfg; }     // conv_tap.hip variant of a tap cfg
+static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || cfg == 15 || cfg == 16 || cfg == 17; }
+static inline int tap_variant(int cfg) { return cfg == 15 ? 6 : cfg == 16 ? 7 : cfg == 17 ? 8 : cfg - kFirstTapCfg; }     // conv_tap.hip variant of a tap cfg
 bool dma_cfg_is_tap(int cfg) { return is_tap_cfg(cfg); }
 bool dma_cfg_f32_ok(int cfg) { return is_tap_cfg(cfg) && conv_tap_f32_ok(tap_variant(cfg)); }
 
@@ -276,6 +277,7 @@ bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok, int ksize, int
     const DmaCfg &k = kCfgs[cfg];
     if (cin_chunks % k.bkc) return false;
     if (is_tap_cfg(cfg) && (ksize != 3 || stride != 1 || !conv_tap_fits(tap_variant(cfg), W))) return false;
+    if (k.na == 32) return cout <= 32 && cout > 16;
     if (k.na == 64) return cout <= 64 && (!is_tap_cfg(cfg) || cout > 32);
     return k.na <= (cout + 127) / 128 * 128 && cout > 64;
 }
@@ -308,6 +310,7 @@ static const TileCost kCost[] = {
     {1.10f, 1.50f, 0.70f, 8.0f},        // 14: 128x128 K32 S3, three per CU: 1x1 layers only (short K, memory / latency bound)
     {1.05f, 1.05f, 1.05f, 18.0f},       // 15: 256x224 tap reuse (7/8 of the 256x256 tile's loop)
     {0.0f, 0.0f, 0.0f, 0.0f},           // 16: 128x128 2-D tap reuse, three per CU (chosen by rule)
+    {0.0f, 0.0f, 0.0f, 0.0f},           // 17: 32x256 2-D tap reuse (chosen by rule)
 };
 
 int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W, bool tap_only) {
@@ -318,6 +321,7 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
         return atoi(force);
 #endif
     const int fallback = v1_ok ? 0 : -1;
+    if (cout <= 32 && M >= 8192 && dma_cfg_valid(17, cout, cin_chunks, v1_ok, ksize, stride, W)) return 17;     // (tiny-YOLOv2 16 -> 32 at 208 x 208)
     if (cout <= 64) {   // narrow, bandwidth-bound layers: 3x3/1 with tap reuse (304x304 32->64: 239 us vs 273 on the 64x512 tile)
         if (M >= 8192 && dma_cfg_valid(13, cout, cin_chunks, v1_ok, ksize, stride, W)) return 13;
         return !tap_only && dma_cfg_valid(7, cout, cin_chunks, v1_ok, ksize, stride, W) && M >= 8192 ? 7 : fallback;
@@ -353,7 +357,7 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
         // (with <= 128 workgroups the 4-wave kernel's split-K wins: 25 vs 49 us at batch 1)
         const long long wg128 = (long long)((M + 127) / 128) * ((cout + 127) / 128);
         if (c == 14 && taps != 1 && !(stride == 2 && wg128 > 128 && wg128 <= 256)) continue;
-        if (c == 7 || c == 13 || c == 16 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
+        if (c == 7 || c == 13 || c == 16 || c == 17 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
         const DmaCfg &k = kCfgs[c];
         // tap-reuse tiles walk the padded position grid: (H+1)(W+1) positions per image (square maps assumed here)
         long long Meff = M;

@@ -624,13 +624,15 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_stream_kernel(const Conv
 // 4 = 128 x (16 x 16) and 5 = 64 x (16 x 16) 2-D tiles for maps wider than 78 (any width)
 // 7 = 128 couts x (8 x 16) 2-D tile at THREE workgroups per CU (48 KiB LDS, <= 80 VGPRs) for wide maps with a short K, where
 // a workgroup spends as long in setup + epilogue as in its K loop (152 x 152 64 -> 128: block trace in profiles/r03_ablation.md)
-static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224, 128};
-static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17, 12};
-static const int kTapVariants = 8;
-static const bool kTapF32[] = {false, false, false, true, false, true, false, false};      // float32 tiles: TP <= 2 (second-level accumulator)
+// 8 = 32 couts x (16 x 16): the one 3x3 layer with 32 filters behind the first conv (tiny-YOLOv2 16 -> 32 at 208 x 208; float32 MFMA is 1/16 of
+// fp16's, so the 64-cout tile's idle half would double a launch that is MFMA-bound)
+static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224, 128, 256};
+static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17, 12, 27};
+static const int kTapVariants = 9;
+static const bool kTapF32[] = {false, false, false, true, false, true, false, false, true};      // float32 tiles: TP <= 2 (second-level accumulator)
 bool conv_tap_splitk_ok(int variant) { return variant == 3; }      // the 128 x 128 tile has the (two-pass) split-K instantiation
 bool conv_tap_pair_ok(int variant, bool f32) { return variant == 3 || (variant == 0 && !f32); }   // in-launch pair split: also the fp16 128 x 256 tile
-bool conv_tap_is2d(int variant) { return variant == 4 || variant == 5 || variant == 7; }
+bool conv_tap_is2d(int variant) { return variant == 4 || variant == 5 || variant == 7 || variant == 8; }
 bool conv_tap_f32_ok(int variant) { return variant >= 0 && variant < kTapVariants && kTapF32[variant]; }
 bool conv_tap_fits(int variant, int W) {
     if (variant < 0 || variant >= kTapVariants) return false;
@@ -648,7 +650,8 @@ bool conv_tap_fits(int variant, int W) {
     X(4, 2, 4, 4, 4, 27, 4, 2) \
     X(5, 1, 8, 4, 2, 27, 4, 2) \
     X(6, 4, 2, 4, 7, 17, 2, 1) \
-    X(7, 2, 4, 4, 2, 12, 6, 2)
+    X(7, 2, 4, 4, 2, 12, 6, 2) \
+    X(8, 1, 8, 2, 2, 27, 4, 2)
 
 const char *conv_tap_symbol(int variant, bool f32) {
     switch (variant) {
@@ -702,7 +705,7 @@ hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
     if (p.ksize != 3 || p.stride != 1 || p.pad != 1 || p.Ho != p.H || p.Wo != p.W || (p.cin_chunks & 3) || !conv_tap_fits(variant, p.W) ||
         (p.f32 && !conv_tap_f32_ok(variant)))
         return hipErrorInvalidValue;
-    if (p.outmode == OUT_POOL2 && ((variant != 4 && variant != 5) || (p.H & 1) || (p.W & 1) || p.has_res || p.ksplit > 1 || !p.vec_out || p.Cout % 16))
+    if (p.outmode == OUT_POOL2 && ((variant != 4 && variant != 5 && variant != 8) || (p.H & 1) || (p.W & 1) || p.has_res || p.ksplit > 1 || !p.vec_out || p.Cout % 16))
         return hipErrorInvalidValue;        // the fused pool lives in the 2-D tiles' epilogue only (plan.cpp asks for it accordingly)
     if (p.stream && conv_tap_stream_ok(p, variant)) return launch_conv_tap_stream(p, variant, s);
     const dim3 grid((unsigned)p.n_blocks, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
@@ -722,6 +725,8 @@ hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
         if (variant == 4 && !p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<false, 2, 4, 4, 4, 27, 4, 3, false>), grid, dim3(512), 0, s, p);
         else if (variant == 5 && !p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<false, 1, 8, 4, 2, 27, 4, 3, false>), grid, dim3(512), 0, s, p);
         else if (variant == 5) hipLaunchKernelGGL((conv3x3_tap_kernel<true, 1, 8, 4, 2, 27, 4, 3, false>), grid, dim3(512), 0, s, p);
+        else if (variant == 8 && !p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<false, 1, 8, 2, 2, 27, 4, 3, false>), grid, dim3(512), 0, s, p);
+        else if (variant == 8) hipLaunchKernelGGL((conv3x3_tap_kernel<true, 1, 8, 2, 2, 27, 4, 3, false>), grid, dim3(512), 0, s, p);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }

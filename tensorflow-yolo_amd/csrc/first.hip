@@ -286,7 +286,129 @@ __global__ void __launch_bounds__(512, 4) first_pool_mfma_kernel(const FirstPara
     }
 }
 
-static bool first_mfma_applies(int dtype, int cout, bool pool) { return dtype == YOLO_DTYPE_F16 && cout == 32 && pool; }
+// ---- float32 nets, fused pool: the same on the float32 matrix instruction --------------------------------------------------------
+// tiny-YOLOv2-VOC's first layer (3 -> 16 + pool, 416 x 416, batch 64) ran 218 us on the VALU kernel: 1.4 TB/s where its 310 MB allow
+// ~70 us.  mfma_f32_16x16x4f32 takes ONE float per lane and operand: k = 4 s + (lane >> 4) for k-step s, so K = 27 is seven k-steps
+// with a single wasted slot, a lane's B value is one ds_read_b32 at a loop-invariant offset (kh, kw, c) from its pixel, the A values
+// are seven registers per 16 couts, and the bias is the C input.  Same tiling as above: persistent workgroups, 8 x 16 pooled outputs
+// per tile, wave w = pooled row w (conv rows 2 w, 2 w + 1 = two accumulators of a lane, columns = lanes fr, fr ^ 1), the input patch
+// as 16-byte (R G B 0) float32 pixels in LDS, fetched one tile ahead through registers.  NT = Cout / 16.
+template <int NT>
+__global__ void __launch_bounds__(512, 4) first_pool_mfma_f32_kernel(const FirstParams p) {
+    constexpr int LD = FM_PX * 4;               // floats per patch row
+    __shared__ __attribute__((aligned(16))) float sIn[FM_INY * LD];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    constexpr int COUT = 16 * NT;
+
+    float a1[NT][7];
+    int koff[7];
+    float4v bias1[NT];
+#pragma unroll
+    for (int st = 0; st < 7; ++st) {
+        const int k = 4 * st + fq;              // (kh, kw, c), c fastest: the K_FIRST packing of the weights
+        const bool live = k < 27;
+        const int kk = live ? k : 0;
+        const int kh = kk / 9, kw = (kk - 9 * kh) / 3, c = kk - 9 * kh - 3 * kw;
+        koff[st] = (kh * FM_PX + kw) * 4 + c;   // a dead slot re-reads element 0: finite, its weight is zero
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float w = p.wgt[kk * COUT + 16 * t + fr];
+            a1[t][st] = live ? w : 0.f;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bias1[t] = *reinterpret_cast<const float4v *>(p.bias + 16 * t + 4 * fq);       // rows 4 fq + j of fragment t
+    for (int i = tid; i < FM_INY * FM_PX; i += 512) *reinterpret_cast<float4v *>(sIn + i * 4) = float4v{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NIN = (FM_INY + 3) / 4;
+    float in_r[NIN];
+    const int in_col = tid & 127, in_row0 = tid >> 7;
+    const bool in_col_ok = in_col < FM_INX * 3;
+    const int in_px = in_col / 3;
+    float *const in_dst = sIn + in_row0 * LD + in_px * 4 + (in_col - 3 * in_px);
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+    auto tile_origin = [&](int tile, int &n, int &py0, int &px0) {
+        const uint32_t tyx = fdiv((uint32_t)tile, p.dXB);
+        const int tx = (int)((uint32_t)tile - tyx * (uint32_t)p.xblocks);
+        n = (int)fdiv(tyx, p.dHp);
+        const int ty = (int)(tyx - (uint32_t)n * (uint32_t)p.tiles_y);
+        py0 = ty * FM_TY; px0 = tx * FM_TX;
+    };
+    auto fetch_input = [&](int tile) {
+        int n, py0, px0;
+        tile_origin(tile, n, py0, px0);
+        const float *img = p.in + (long long)n * p.H * p.W * 3;
+        const int gy0 = 2 * py0 - 1 + in_row0, gx3 = (2 * px0 - 1) * 3 + in_col;
+        const bool xok = in_col_ok && (unsigned)gx3 < (unsigned)(3 * p.W);
+        const int w3 = 3 * p.W;
+#pragma unroll
+        for (int it = 0; it < NIN; ++it) {
+            const int gy = gy0 + 4 * it;
+            const bool ok = xok && (unsigned)gy < (unsigned)p.H && (4 * it + in_row0 < FM_INY);
+            const float v = img[ok ? gy * w3 + gx3 : 0];
+            in_r[it] = ok ? v : 0.f;
+        }
+    };
+
+    int tile = blockIdx.x;
+    fetch_input(tile);
+    __syncthreads();            // the zero fill is ordered before the first tile's stores
+    for (; tile < p.n_tiles; tile += gridDim.x) {
+        int n, py0, px0;
+        tile_origin(tile, n, py0, px0);
+#pragma unroll
+        for (int it = 0; it < NIN; ++it)
+            if (in_col_ok && 4 * it + in_row0 < FM_INY) in_dst[4 * it * LD] = in_r[it];
+        __syncthreads();        // input patch visible
+        if (tile + (int)gridDim.x < p.n_tiles) fetch_input(tile + gridDim.x);
+        const int oy = py0 + wave;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4v m[NT];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float *src = sIn + (2 * wave + r) * LD + (16 * half + fr) * 4;
+                float b[7];
+#pragma unroll
+                for (int st = 0; st < 7; ++st) b[st] = src[koff[st]];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float4v d = bias1[t];
+#pragma unroll
+                    for (int st = 0; st < 7; ++st) d = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t][st], b[st], d, 0, 0, 0);
+                    if (r == 0) m[t] = d;
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) m[t][j] = fmaxf(m[t][j], d[j]);
+                    }
+                }
+            }
+            const int ox = px0 + 8 * half + (fr >> 1);
+            const bool store = !(fr & 1) && oy < Hp && ox < Wp;
+            float *op = reinterpret_cast<float *>(p.out) + (long long)n * p.out_img_stride + ((long long)oy * Wp + ox) * p.out_ld + 4 * fq;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float4v v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = fmaxf(m[t][j], __shfl_xor(m[t][j], 1));       // columns ox, ox ^ 1
+                    if (p.leaky) x = fmaxf(0.1f * x, x);
+                    v[j] = x;
+                }
+                if (store) *reinterpret_cast<float4v *>(op + 16 * t) = v;
+            }
+        }
+        __syncthreads();        // every wave has read its patch rows: the next tile may overwrite them
+    }
+}
+
+// the matrix-core forms of layer 1 + pool: fp16 nets with 32 couts, float32 nets with 16 or 32 (16-byte aligned float32 output view)
+static bool first_mfma_applies(int dtype, int cout, bool pool) {
+    return pool && (dtype == YOLO_DTYPE_F16 ? cout == 32 : (cout == 16 || cout == 32));
+}
 
 template <bool T, int COUT>
 static void launch_first_t(const FirstParams &p, dim3 grid, hipStream_t s) {
@@ -318,7 +440,10 @@ hipError_t launch_first(const FirstParams &p0, int dtype, hipStream_t s) {
         const long long tiles = p.total / ((long long)p.H * p.W) * p.xblocks * p.tiles_y;
         if (tiles < 1 || tiles > 0x7fffffffLL || (long long)p.H * p.W * 3 > 0x7fffffffLL) return hipErrorInvalidValue;
         p.n_tiles = (int)tiles;
-        hipLaunchKernelGGL(first_pool_mfma_kernel, dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(512), 0, s, p);
+        const dim3 mgrid((unsigned)(tiles < 1024 ? tiles : 1024));
+        if (dtype == YOLO_DTYPE_F16) hipLaunchKernelGGL(first_pool_mfma_kernel, mgrid, dim3(512), 0, s, p);
+        else if (p.Cout == 16) hipLaunchKernelGGL(first_pool_mfma_f32_kernel<1>, mgrid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL(first_pool_mfma_f32_kernel<2>, mgrid, dim3(512), 0, s, p);
         return hipGetLastError();
     }
     const dim3 grid((unsigned)g);
@@ -335,7 +460,9 @@ hipError_t launch_first(const FirstParams &p0, int dtype, hipStream_t s) {
 }
 
 std::string first_symbol(int dtype, int cout, bool pool) {
-    if (first_mfma_applies(dtype, cout, pool)) return "yolo::first_pool_mfma_kernel(yolo::FirstParams)";
+    if (first_mfma_applies(dtype, cout, pool))
+        return dtype == YOLO_DTYPE_F16 ? "yolo::first_pool_mfma_kernel(yolo::FirstParams)"
+                                       : std::string("void yolo::first_pool_mfma_f32_kernel<") + std::to_string(cout / 16) + ">(yolo::FirstParams)";
     return std::string("void yolo::conv_first_kernel<") + (dtype == YOLO_DTYPE_F16 ? "false" : "true") + ", " + std::to_string(cout) + ", " +
            (pool ? "true" : "false") + ">(yolo::FirstParams)";
 }

@@ -437,15 +437,15 @@ struct Planner {
                     L[s].W % 2 == 0 && L[s].W >= 96 && !getenv("YOLO_NO_CONV_POOL")) {
                     Kernel &c = net->kernels.back();
                     const bool f16 = net->opt.dtype == YOLO_DTYPE_F16;
-                    const bool tile13 = c.cout == 64, tile12 = c.cout > 64 && f16;       // (the float32 2-D tile exists for 64 couts only)
+                    const bool tile13 = c.cout == 64, tile17 = c.cout == 32, tile12 = c.cout > 64 && f16;       // (the float32 2-D tiles: 64 and 32 couts)
                     if (c.ksize == 3 && c.stride == 1 && c.outmode == OUT_NORMAL && !c.has_res && !c.head && !c.stem && !has_claim[s] &&
-                        c.cpt % 4 == 0 && c.cout % 16 == 0 && (tile13 || tile12)) {
+                        c.cpt % 4 == 0 && c.cout % 16 == 0 && (tile13 || tile12 || tile17)) {
                         View pv = out_view_for(i);
                         if (!pv.f32 && pv.ld % epc == 0 && (pv.base + pv.coff) % epc == 0 && pv.img_stride % epc == 0) {
                             c.outmode = OUT_POOL2;
                             c.out = pv;
                             c.layer = i;
-                            c.tile = tile13 ? 13 : 12;
+                            c.tile = tile13 ? 13 : tile17 ? 17 : 12;
                             c.note += " + fused 2x2/2 max-pool (layer " + std::to_string(i) + ")";
                             if (has_claim[i]) c.note += " -> concat slice";
                             L[i].view = pv; L[i].materialised = true;

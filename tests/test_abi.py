@@ -64,7 +64,7 @@ def test_plan_yolov2_and_tiny():
     assert "fused: reorg x2" in d and d.count("concat slice") == 2
     tiny = v2.create_tiny_network(np.reshape(cases.VOC_TINY_ANCHORS, [-1, 2]), NAMES80[:20], False)
     pt = engine.Plan(tiny, dtype="fp32", max_batch=64)
-    assert pt.weight_count == 15867885 and pt.num_kernels == 9 + 4      # (pool 1 in conv_first, pool 3 in the 104 x 104 conv)
+    assert pt.weight_count == 15867885 and pt.num_kernels == 9 + 3      # (pool 1 in conv_first, pools 2 and 3 in the 2-D tap tiles of the 208 / 104 convs)
 
 
 def test_fallback_graph_plans():

@@ -188,6 +188,23 @@ def test_conv_maxpool_fused_in_2d_tap_tiles(dtype):
     check_graph(g, x, dtype, seed=6, read=(2, 4))
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+def test_conv_maxpool_fused_32_cout_tile(dtype):
+    """the 32-cout 2-D tap tile (tiny-YOLOv2's second conv, 16 -> 32 at 208 x 208 + max-pool): float32 with ONE 16-channel slice
+    (K loop of nine taps), fp16 with one 32-channel slice; partial tiles, pool fused, the unfused plan gives the same values"""
+    cin = 16 if dtype == "fp32" else 32
+    g = new_graph(26, 104, cin)
+    g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))                  # 1
+    g.append(PL.max_pool2d(g[-1].out, 2, 2))                         # 2  fused into 1 (tile 17)
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 1, 1))                  # 3
+    x = synth.synthetic_input(4, 26, 104, cin, seed=19)
+    eng = check_graph(g, x, dtype, seed=8)
+    names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
+    assert "32x256,tap9,2d,x2>+pool" in names and eng.describe().count("fused 2x2/2 max-pool") == 1, names
+    eng2 = check_graph(g, x, dtype, seed=8, read=(1, 2))
+    assert "32x256,tap9,2d,x2>" in " ".join(ki.name.decode() for ki in eng2.kernel_infos())
+
+
 @pytest.mark.parametrize("hw", [(20, 44), (32, 64), (6, 130)])
 def test_first_layer_pool_on_the_matrix_cores(hw):
     """Darknet-19's first layer + pool in fp16 nets (conv 3x3/1 3 -> 32 + BN + leaky + 2x2/2 max-pool): first_pool_mfma_kernel
@@ -284,7 +301,7 @@ def test_fused_stem(shape):
     assert ("conv_stem<f16,3-32-64>" in names2) == (H % 2 == 0 and W % 2 == 0) and "3-32-64-32" not in names2, names2
 
 
-@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15, 16])
+@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15, 16, 17])
 def test_tap_reuse_tile_configs(tile):
     """tap-reuse tiles of conv_tap.hip (3x3/1 only: patch of 1, 2, 4 and 6 channel slices, image borders inside a
     block, position tail; the other layers fall back to the default choice) forced through yolo_net_options.force_tile: K-stage counts 1, 2 (shorter than the
@@ -313,8 +330,8 @@ def test_tap_reuse_tile_configs(tile):
 
 
 @pytest.mark.parametrize("shape", [(2, 19, 19, 512, 256), (3, 38, 38, 64, 128), (1, 76, 76, 128, 256), (2, 7, 78, 32, 128),
-                                   (2, 5, 110, 64, 128), (1, 9, 152, 64, 128), (2, 33, 100, 32, 64), (1, 48, 304, 32, 64)])
-@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15, 16])
+                                   (2, 5, 110, 64, 128), (1, 9, 152, 64, 128), (2, 33, 100, 32, 64), (1, 48, 304, 32, 64), (2, 21, 70, 32, 32)])
+@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15, 16, 17])
 def test_tap_reuse_conv_shapes(shape, tile):
     """conv_tap.hip on the feature-map sizes of YOLOv3-608 (19, 38, 76), the widest rows its padded-linear tiles take
     (78, 110, 158 >= 152), wide maps for the 2-D tiles (partial 16x16 tiles in both directions, Cout 64) and a residual
@@ -328,13 +345,13 @@ def test_tap_reuse_conv_shapes(shape, tile):
     g.append(PL.max_pool2d(g[-1].out, 2, stride=1))
     x = synth.synthetic_input(B, H, W, cin, seed=21)
     eng = check_graph(g, x, "fp16", seed=5, read=(1, 4), tile=tile)
-    if tile in (11, 13):        # the float32 tiles (16-channel slices, fp32 FMA chains restarted every 288 k: conv_common.h flush_acc): 1e-4 contract
+    if tile in (11, 13, 17):    # the float32 tiles (16-channel slices, fp32 FMA chains restarted every 288 k: conv_common.h flush_acc): 1e-4 contract
         eng32 = check_graph(g, x, "fp32", seed=5, read=(1, 4), tile=tile)
-        if dict(((11, cout > 64 and W <= 158), (13, cout == 64)))[tile]:
+        if dict(((11, cout > 64 and W <= 158), (13, cout == 64), (17, cout == 32)))[tile]:
             assert "tap9" in " ".join(ki.name.decode() for ki in eng32.kernel_infos())
     names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
-    max_w = {8: 78, 9: 78, 10: 110, 11: 158, 12: 1 << 20, 13: 1 << 20, 15: 22, 16: 1 << 20}[tile]
-    need = {8: cout > 64, 9: cout >= 256, 10: cout > 64, 11: cout > 64, 12: cout > 64, 13: cout == 64, 15: cout >= 256, 16: cout > 64}[tile]
+    max_w = {8: 78, 9: 78, 10: 110, 11: 158, 12: 1 << 20, 13: 1 << 20, 15: 22, 16: 1 << 20, 17: 1 << 20}[tile]
+    need = {8: cout > 64, 9: cout >= 256, 10: cout > 64, 11: cout > 64, 12: cout > 64, 13: cout == 64, 15: cout >= 256, 16: cout > 64, 17: cout == 32}[tile]
     if W <= max_w and need:             # else: the forced tile is not valid for this layer, the default one runs
         assert "tap9" in names, names
 
