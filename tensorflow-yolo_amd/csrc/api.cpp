@@ -288,7 +288,10 @@ int choose_ksplit(const Kernel &k, const ConvParams &p, int tile, size_t slab_by
     // launch reads anyway (measured: YOLOv2 13x13 at batch 1, 22 MB of partials beside 38 MB of weights, 553 -> 70 us; YOLOv3 19x19
     // at batch 8, 47 MB beside 9 MB, slower than unsplit); a few MB are always fine (L2-resident, ~2 us)
     const size_t wbytes = (size_t)p.Cout * (size_t)p.taps * (size_t)p.cin_chunks * 16;
-    while (ks >= 2 && ((size_t)ks * (size_t)p.M * cout_pad * 4 > slab_bytes || (size_t)ks * (size_t)p.M * cout_pad * 4 > (2 * wbytes > ((size_t)8 << 20) ? 2 * wbytes : ((size_t)8 << 20)))) --ks;
+    // (1x1 layers: up to 24 MB -- tiny-YOLOv2's head 1024 -> 125 at 13x13, batch 64, is 85 workgroups walking K = 1024 alone: 85 us whole,
+    // 53 us as four splits with 22 MB of partial sums)
+    const size_t small_cap = (size_t)(p.taps == 1 ? 24 : 8) << 20;
+    while (ks >= 2 && ((size_t)ks * (size_t)p.M * cout_pad * 4 > slab_bytes || (size_t)ks * (size_t)p.M * cout_pad * 4 > (2 * wbytes > small_cap ? 2 * wbytes : small_cap))) --ks;
     if (ks < 2) return 1;
     ku = (int)((units + ks - 1) / ks);
     return (units + ku - 1) / ku;       // every split owns at least one unit
