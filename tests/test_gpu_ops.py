@@ -356,6 +356,36 @@ def test_tap_reuse_conv_shapes(shape, tile):
         assert "tap9" in names, names
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+def test_random_layer_shapes_through_the_default_rules(dtype):
+    """Seeded random conv stacks through the built-in tile rules (no forced tile): map sizes around the rule boundaries (13/14, 96,
+    110, 152 columns), channel counts 16..1024, batches that put a launch on either side of the 128 / 256 / 512-workgroup limits,
+    stride 2, residuals and pools -- every layer read back and compared with the oracle."""
+    rng = np.random.RandomState(1234 if dtype == "fp16" else 4321)
+    widths = [13, 14, 19, 26, 38, 52, 76, 96, 104, 112, 152]
+    chans = [32, 64, 128, 256] if dtype == "fp16" else [16, 32, 64, 128]
+    for case in range(10):
+        W = int(widths[rng.randint(len(widths))])
+        H = int(rng.randint(6, 20)) if W > 60 else W
+        B = int(rng.randint(1, 7))
+        cin = int(chans[rng.randint(len(chans))])
+        c1 = int(chans[rng.randint(len(chans))])
+        g = new_graph(H, W, cin)
+        g.append(PL.conv2d_bn_act(g[-1].out, c1, 3, 1))                                  # 1
+        g.append(PL.conv2d_bn_act(g[-1].out, max(16, c1 // 2) if dtype == "fp32" else max(32, c1 // 2), 1, 1))     # 2
+        g.append(PL.conv2d_bn_act(g[-1].out, c1, 3, 1))                                  # 3
+        g.append(PL.shortcut(g[-1].out, g[-3].out))                                      # 4
+        read = [1, 4]
+        if H % 2 == 0 and W % 2 == 0 and rng.randint(2):
+            g.append(PL.max_pool2d(g[-1].out, 2, 2))                                     # 5
+        else:
+            g.append(PL.conv2d_bn_act(g[-1].out, min(1024, 2 * c1), 3, 2))               # 5
+        g.append(PL.conv2d_bn_act(g[-1].out, 64, 1, 1))                                  # 6
+        x = synth.synthetic_input(B, H, W, cin, seed=100 + case)
+        print("case", case, (B, H, W, cin, c1))
+        check_graph(g, x, dtype, seed=40 + case, read=tuple(read))
+
+
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 14])
 def test_every_dma_tile_config(tile):
     """each LDS-DMA tile shape of conv_dma.hip, forced through yolo_net_options.force_tile (a tile
