@@ -18,9 +18,11 @@ IMAGE_EXTENSIONS = ("jpg", "bmp", "png", "gif")
 class BoundingBox(object):
     """Same fields and helpers as the reference's result type (net/base.py:257-272)."""
 
+    __slots__ = ("x", "y", "w", "h", "cx", "cy", "class_idx", "prob")     # (a batch of YOLOv3-608 yields ~3 000 of these)
+
     def __init__(self, x=0., y=0., w=0., h=0., cx=0, cy=0, class_idx=-1, prob=-1.):
-        self.x, self.y, self.w, self.h = x, y, w, h
-        self.cx, self.cy = cx, cy
+        self.x = x; self.y = y; self.w = w; self.h = h
+        self.cx = cx; self.cy = cy
         self.class_idx = class_idx
         self.prob = prob
 
@@ -36,7 +38,7 @@ class BoundingBox(object):
 
 
 def boxes_from_records(records):
-    return [[BoundingBox(x=r[0], y=r[1], w=r[2], h=r[3], class_idx=r[4], prob=r[5]) for r in img] for img in records]
+    return [[BoundingBox(r[0], r[1], r[2], r[3], 0, 0, r[4], r[5]) for r in img] for img in records]
 
 
 def non_maximum_suppression(boxes, iou_threshold, per_class=False):
