@@ -90,8 +90,8 @@ typedef struct yolo_net_options {
                              * parts on the caller's + internal streams (overlaps the kernels' tails; the
                              * environment variable YOLO_STREAMS sets the default when this is 0)          */
     int32_t force_tile;     /* 0: per-layer tile choice (cost model / autotune); t + 1: run conv tile id t on every
-                             * conv layer that accepts it (0 = 4-wave kernel, 1-7 and 14 LDS-DMA tiles, 8-13 tap-reuse
-                             * tiles): test and tuning hook, any value gives the same results up to summation order   */
+                             * conv layer that accepts it (0 = 4-wave kernel, 1-7 and 14 LDS-DMA tiles, 8-13 and 15-17
+                             * tap-reuse tiles): test and tuning hook, any value gives the same results up to summation order   */
     int32_t reserved[1];
 } yolo_net_options;
 
