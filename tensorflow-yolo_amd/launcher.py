@@ -5,7 +5,7 @@ Keeps the reference launcher's surface (reference launcher.py:15-60): the two fl
 COMMON / ANCHOR / TRAIN / TEST merged as {**section, **COMMON}, relative `*_dir` / `*_path` values
 resolved against the .ini's directory, `anchors` / `class_names` parsed as Python literals, and the
 network picked by COMMON.version.  Only `test` runs on this backend; `train` and `anchor` end with a
-clear message.  Extra, optional keys: `dtype` (fp32 | fp16), `nms_mode` (agnostic | per_class), `max_boxes` / `cand_capacity` (record caps);
+clear message.  Extra, optional keys: `dtype` (fp32 | fp16), `nms_mode` (agnostic | per_class), `max_boxes` / `cand_capacity` (record caps), `autotune` (True: per-layer tile timing at start-up);
 version additionally accepts `v2-tiny`.  `--section` selects another TEST-like section (the
 reference's yolo_2.ini keeps its COCO settings in [TEST_COCO], which no mode reaches there).
 """

@@ -148,6 +148,9 @@ class Yolo(object):
             type(self).load_weights(self.net, pretrained_weights_path)
             print("Pre-trained weights loaded.")
 
+        if str(params.get("autotune", "false")).lower() == "true":      # new optional key: time every conv tile per layer once, on a
+            eng = self.net.engine                                         # full batch of this shape (yolo_net_autotune), instead of the built-in rules
+            eng.autotune(np.zeros((eng.max_batch,) + tuple(input_shape), dtype=np.float32))
         # resize / colour order / /255 run on the device with OpenCV's INTER_LINEAR arithmetic (base.preprocess_image_gpu);
         # `preprocess = pillow` (new optional key) keeps the host-side Pillow resampler
         batches = base.generate_test_batch if str(params.get("preprocess", "gpu")).lower() == "pillow" else base.generate_test_batch_gpu
