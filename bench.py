@@ -14,14 +14,17 @@ records when N > 1].  Images shard over ranks (weak scaling: every rank runs the
 child's stdout, the exit code is the child's).
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "parity":       the metric's second half, "post-NMS box-set match vs CPU ref": two images through the HIP path and
-                  through the CPU fp32 oracle pipeline OUTSIDE the timed region -- max |logit - oracle logit| and the
-                  post-NMS box sets compared under the margin rule of oracle/parity.py
+  "parity":       the metric's second half, "post-NMS box-set match vs CPU ref": EVERY image of the first timed batch through the
+                  TIMED engine (same plan, same batch size) and through the CPU fp32 oracle pipeline OUTSIDE the timed region --
+                  max |logit - oracle logit| against a bound the HIP path cannot influence and the post-NMS box sets under the
+                  gate of oracle/parity.py
   "roofline":     dominant kernel family (the implicit-GEMM conv tile with most device time): algorithmic FLOPs of its launches
                   / their device time measured with hipEvents on the launch stream (instrumented steps
                   run right after the timed region; the events add bubbles so they never time `value`)
   "cpu_baseline": the CPU oracle (torch-CPU restatement of the reference's TF path + NumPy decode/NMS,
-                  kind "port") timed on the host cores on a bounded sample of the same workload.
+                  kind "port") timed on the host cores on the same batch: forward and decode + NMS apart.
+  "one_stream":   (N = 1, when the timed engine runs the batch as parts on several streams) the same K steps on one stream,
+                  timed right before and right after the timed region.
 """
 import argparse
 import json
@@ -43,6 +46,10 @@ WORKLOADS = {
     "v3-416-b32-fp16": ("v3", 416, 32, "fp16"),
     "v3-608-b8-fp16": ("v3", 608, 8, "fp16"),       # smaller batches of the headline net (tile-choice sanity, latency)
     "v3-608-b1-fp16": ("v3", 608, 1, "fp16"),
+    "v3-608-b16-fp16": ("v3", 608, 16, "fp16"),     # points for the one-stream / two-stream rule (DESIGN.md "Kernel boundaries")
+    "v3-416-b16-fp16": ("v3", 416, 16, "fp16"),
+    "v2-416-b32-fp16": ("v2", 416, 32, "fp16"),
+    "v2-416-b64-fp16": ("v2", 416, 64, "fp16"),
 }
 PEAK = {"fp16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s, MI355X_MICROARCH.md "Chip-level parameters"
 COCO_V2 = [0.57273, 0.677385, 1.87446, 2.06253, 3.33843, 5.47434, 7.88282, 3.52778, 9.77052, 9.16828]
@@ -66,30 +73,21 @@ def make_model(kind, size, batch, dtype, seed=0, streams=0, max_boxes=256, **eng
     return model, w, anchors, ncls
 
 
-def two_stream_leg(kind, size, batch, dtype, w, xs, args):
-    """The same K steps with the batch run as two independent halves on two HIP streams (yolo_net_options.streams = 2,
-    DESIGN.md "Kernel boundaries"): the kernels' tails and launch boundaries of one half overlap the other half's kernels.
-    Reported BESIDE `value` (which stays the one-stream number the per-launch `roofline` figures belong to)."""
+def timed_steps(eng, xs, steps, warmup, threshold, iou_threshold):
+    """W untimed + K timed steps of one engine on this process's GPU (no process group): the one-stream comparison legs."""
     import torch
-    from tensorflow_yolo_amd import YoloV2, YoloV2Tiny, YoloV3
     from tensorflow_yolo_amd.net import dist as ydist
-    cls, anchors, ncls = {"v3": (YoloV3, COCO_V3, 80), "v2": (YoloV2, COCO_V2, 80), "v2-tiny": (YoloV2Tiny, VOC_TINY, 20)}[kind]
-    model = cls()
-    model.build(anchors, ["c%d" % i for i in range(ncls)], (size, size, 3), dtype=dtype, max_batch=batch, weights=w, streams=2,
-                max_boxes=args.max_boxes)
-    eng = model.net.engine
-    for i in range(args.warmup):
-        ydist.detect_sharded(eng, xs[i & 1], args.threshold, args.iou_threshold)
+    for i in range(warmup):
+        ydist.detect_sharded(eng, xs[i & 1], threshold, iou_threshold)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        _, _, status = ydist.detect_sharded(eng, xs[i & 1], args.threshold, args.iou_threshold)
+    for i in range(steps):
+        _, _, status = ydist.detect_sharded(eng, xs[i & 1], threshold, iou_threshold)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if status.cpu().numpy().any():
-        raise RuntimeError("two-stream leg: record capacity exceeded")
-    return {"streams": 2, "value": round(args.steps * batch / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "note": "same build, same inputs and K steps, batch as two halves on two HIP streams (opt-in mode; `value` is the one-stream run)"}
+        raise RuntimeError("comparison leg: record capacity exceeded")
+    return dt
 
 
 def cpu_model():
@@ -102,15 +100,21 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(kind, size, w, anchors, ncls, budget_s=20.0, time_it=True):
-    """Oracle forward + decode + NMS on the host cores, bounded sample (never the thing shipped).
-    Returns (cpu_baseline dict or None, x [2 images], oracle fp32 logits of x) -- the logits feed the parity check."""
+# the REFERENCE's own decode + NMS functions (net/v2.py:83-119, net/v3.py:109-151, net/base.py:195-209),
+# imported and timed in the survey session on that container's host (Intel Xeon @ 2.10 GHz, 8 vCPU, one Python thread,
+# NumPy 2.2.6, synthetic randn heads).  Quoted, not re-measured: the reference does not travel to the GPU box.
+SURVEY_REFERENCE_DECODE_NMS_MS = {"v2-416": 7.1, "v3-416": 70.4, "v3-608": 168.6}
+
+
+def cpu_baseline(kind, size, w, anchors, ncls, x, dtype, budget_s=24.0, time_it=True):
+    """Oracle forward + decode + NMS on the host cores over the images `x` (the bench's own first batch), never the thing
+    shipped.  Returns (cpu_baseline dict or None, oracle fp32 logits of x, e_ref) -- the logits and e_ref (what fp16 storage
+    alone does to them, per the oracle: parity.py) feed the parity check of the timed plan."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import to_oracle
     from oracle import decode_ref, forward_ref
     from tensorflow_yolo_amd import YoloV2, YoloV2Tiny, YoloV3
-    from tensorflow_yolo_amd.net import synth
     cls = {"v3": YoloV3, "v2": YoloV2, "v2-tiny": YoloV2Tiny}[kind]
     names = ["c%d" % i for i in range(ncls)]
     net = cls.create_network(np.reshape(anchors, [-1, 2]), names, False, input_shape=(size, size, 3))
@@ -121,47 +125,122 @@ def cpu_baseline(kind, size, w, anchors, ncls, budget_s=20.0, time_it=True):
     default_threads = torch.get_num_threads()
     cores = max(1, min(32, default_threads))
     torch.set_num_threads(cores)
-    chunk = 2
-    x = synth.synthetic_input(chunk, size, size, 3, seed=123)
+    n_img = x.shape[0]
+    chunk = 2 if size >= 416 else 4
+    sc = decode_ref.v3_scales(anchors, (size, size)) if kind == "v3" else None
 
-    def one():
-        logits = forward_ref.forward(L, Wd, x)
+    def decode(logits, full_scan=False):
         if kind == "v3":
-            sc = decode_ref.v3_scales(anchors, (size, size))
-            decode_ref.find_bounding_boxes_v3(logits, 0.5, 0.6, sc)
-        else:
-            decode_ref.find_bounding_boxes_v2(logits, 0.5, 0.6, anchors, ncls)
-        return logits
+            return decode_ref.find_bounding_boxes_v3(logits, 0.5, 0.6, sc, full_scan=full_scan)
+        return decode_ref.find_bounding_boxes_v2(logits, 0.5, 0.6, anchors, ncls, full_scan=full_scan)
 
-    ref_logits = one()                      # warm-up (thread pool, allocator); its logits are the parity reference
-    if not time_it:
-        torch.set_num_threads(default_threads)
-        return None, x, ref_logits
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        one()
-        n += chunk
-        dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 64:
-            break
+    forward_ref.forward(L, Wd, x[:min(chunk, n_img)])          # warm-up (thread pool, allocator)
+    ref = []
+    t_fwd = t_dec = 0.0
+    n_timed = 0
+    t_all = time.perf_counter()
+    for i in range(0, n_img, chunk):                            # first pass: every image once (its logits are the parity reference)
+        t0 = time.perf_counter()
+        lg = forward_ref.forward(L, Wd, x[i:i + chunk])
+        t1 = time.perf_counter()
+        decode(lg)
+        t2 = time.perf_counter()
+        ref.append(lg)
+        t_fwd += t1 - t0; t_dec += t2 - t1; n_timed += lg.shape[0]
+    while time_it and time.perf_counter() - t_all < 10.0:       # small workloads: keep going until ~10 s of CPU work are on the clock
+        for i in range(0, n_img, chunk):
+            t0 = time.perf_counter()
+            lg = forward_ref.forward(L, Wd, x[i:i + chunk])
+            t1 = time.perf_counter()
+            decode(lg)
+            t2 = time.perf_counter()
+            t_fwd += t1 - t0; t_dec += t2 - t1; n_timed += lg.shape[0]
+            if time.perf_counter() - t_all > budget_s:
+                break
+    ref_logits = np.concatenate(ref)
+    e_ref = None
+    if dtype == "fp16":     # (not part of the timed baseline: the oracle with the HIP path's storage roundings, for the parity bands)
+        e_ref = 0.0
+        for i in range(0, n_img, chunk):
+            l16 = forward_ref.forward(L, Wd, x[i:i + chunk], storage="fp16")
+            e_ref = max(e_ref, float(np.max(np.abs(l16.astype(np.float64) - ref_logits[i:i + chunk]))))
+    base = None
+    if time_it:
+        torch.set_num_threads(1)
+        # decode + NMS the way the reference runs it: the Python scan over EVERY cell (net/v3.py:113-136), one thread
+        k = min(2, n_img)
+        t0 = time.perf_counter()
+        decode(ref_logits[:k], full_scan=True)
+        full_ms = (time.perf_counter() - t0) / k * 1e3
+        key = "%s-%d" % ("v2" if kind != "v3" else "v3", size)
+        base = {"value": round(n_timed / (t_fwd + t_dec), 3), "unit": "images/sec", "cores": int(cores), "kind": "port",
+                "forward_img_s": round(n_timed / t_fwd, 3),
+                "decode_nms_ms_per_image": round(full_ms, 2),
+                "decode_nms_prefiltered_ms_per_image": round(t_dec / n_timed * 1e3, 3),
+                "reference_code_decode_nms_ms_per_image": SURVEY_REFERENCE_DECODE_NMS_MS.get(key if kind != "v2-tiny" else ""),
+                "reference_code_source": "SURVEY.md section 6: the reference's own net/v2.py:83-119 / net/v3.py:109-151 + net/base.py:195-209, "
+                                         "timed in the survey container (Xeon 2.1 GHz, 1 thread, NumPy 2.2.6); not re-measurable on the GPU box",
+                "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
+                "sample": "%d images %dx%d (the timed batch, %d distinct), CPU oracle: torch-CPU fp32 restatement of the reference's TF path on %d "
+                          "threads (forward_img_s) + NumPy decode/NMS restatement (value = both; decode_nms_ms_per_image = the full per-cell "
+                          "Python scan as the reference runs it, 1 thread, %d image(s); *_prefiltered = the oracle's vectorised pre-filter "
+                          "form used inside value), not TensorFlow, %.1f s" % (n_timed, size, size, n_img, cores, k, t_fwd + t_dec)}
     torch.set_num_threads(default_threads)
-    return ({"value": round(n / dt, 3), "unit": "images/sec", "cores": int(cores), "kind": "port",
-             "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
-             "sample": "%d images %dx%d, CPU oracle (torch-CPU fp32 restatement of the reference's TF path + NumPy decode/NMS, "
-                       "not TensorFlow), %.1f s" % (n, size, size, dt)}, x, ref_logits)
+    return base, ref_logits, e_ref
 
 
-def parity_report(model, kind, size, anchors, ncls, x, ref_logits, threshold, iou_threshold):
-    """HIP path vs the CPU fp32 oracle pipeline on the images `x` (oracle/parity.py); outside the timed region."""
+def parity_report(eng, kind, size, anchors, ncls, x, ref_logits, threshold, iou_threshold, dtype, e_ref):
+    """The TIMED plan (same engine, same batch size, every image of the batch distinct) vs the CPU fp32 oracle pipeline
+    (oracle/parity.py); outside the timed region."""
     from oracle import decode_ref, parity
     from tensorflow_yolo_amd.net import engine as yengine
-    eng = model.net.engine
     got_logits = eng.forward(x).cpu().numpy()
     recs, _ = yengine.records_to_host(*eng.detect(x, threshold, iou_threshold))
+    bound = dict(e_ref=e_ref) if dtype == "fp16" else dict(abs_bound=1e-4)
     if kind == "v3":
-        return parity.check(ref_logits, got_logits, recs, 3, threshold, iou_threshold, scales=decode_ref.v3_scales(anchors, (size, size)))
-    return parity.check(ref_logits, got_logits, recs, 2, threshold, iou_threshold, anchors=anchors, num_classes=ncls)
+        rep = parity.check(ref_logits, got_logits, recs, 3, threshold, iou_threshold, scales=decode_ref.v3_scales(anchors, (size, size)), **bound)
+    else:
+        rep = parity.check(ref_logits, got_logits, recs, 2, threshold, iou_threshold, anchors=anchors, num_classes=ncls, **bound)
+    rep["plan"] = "the timed engine: batch %d, %d stream(s)" % (x.shape[0], eng.num_streams)
+    return rep
+
+
+def timed_region(step, steps, warmup, world, device_sync, reduce_device):
+    """The bench contract's timed region: W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier +
+    device synchronise on both sides; the MAX over ranks is the job's time.  Returns (elapsed seconds, result of the last step).
+    (A function of its own so that the world-2 gloo test drives the very code the GPU run times: tests/test_dist_cpu.py.)"""
+    import torch
+    import torch.distributed as dist
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        device_sync()
+
+    for i in range(warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(steps):
+        last = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, last
+
+
+def contract_fields(rank, world, steps, warmup, batch, elapsed, dtype):
+    """The contract's fields of the ONE line rank 0 prints (None on every other rank): whole-job images/sec over all ranks."""
+    if rank != 0:
+        return None
+    return {"metric": "images/sec at 1/2/4/8 MI355X + post-NMS box-set match vs CPU ref",
+            "value": round(steps * batch * world / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16" if dtype == "fp16" else "f32", "data": "synthetic"}
 
 
 def launch_workers(n):
@@ -186,13 +265,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="v3-608-b32-fp16", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-parity", action="store_true", help="skip the 2-image parity check against the CPU oracle")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity check of the timed plan against the CPU oracle")
     ap.add_argument("--force-tile", type=int, default=None, help="tuning hook: yolo_net_options.force_tile (one conv tile id wherever valid)")
     ap.add_argument("--max-boxes", type=int, default=256, help="box records per image (SURVEY 8e: K_max = 256 -> 196.7 KB per rank)")
     ap.add_argument("--autotune", action="store_true", help="time every conv tile per layer on the device first (default: built-in rules)")
-    ap.add_argument("--streams", type=int, default=0, help="run every batch as this many independent parts on as many HIP streams "
-                    "(overlaps the kernels' tails; the per-kernel roofline figures then describe one part's launches run alone)")
-    ap.add_argument("--no-two-stream-leg", action="store_true", help="skip the extra timed leg with --streams 2 (N = 1 only)")
+    ap.add_argument("--streams", type=int, default=0, help="yolo_net_options.streams: 0 = the library's rule (two half batches on two HIP "
+                    "streams where that was measured faster, e.g. the headline workload; config.streams says what ran), 1 = one pass, "
+                    "2..4 = that many parts.  The per-kernel roofline figures are always those of whole-batch launches run alone (streams = 1)")
+    ap.add_argument("--no-one-stream-leg", action="store_true", help="skip the one-stream comparison legs around the timed region (N = 1, "
+                    "only when the timed engine runs on more than one stream)")
     ap.add_argument("--threshold", type=float, default=0.5)
     ap.add_argument("--iou-threshold", type=float, default=0.6)
     ap.add_argument("--dump-kernels", default=None, help="write the per-kernel timing table (JSON) here")
@@ -226,48 +307,53 @@ def main():
     eng = model.net.engine
     from tensorflow_yolo_amd.net import synth
     # two different resident input batches, alternated, so no step re-reads the previous step's input
-    xs = [torch.from_numpy(synth.synthetic_input(batch, size, size, 3, seed=1000 + 17 * rank + i)).to(dev) for i in range(2)]
+    xs_host = [synth.synthetic_input(batch, size, size, 3, seed=1000 + 17 * rank + i) for i in range(2)]
+    xs = [torch.from_numpy(x).to(dev) for x in xs_host]
     if args.autotune:
         eng.autotune(xs[0])     # per-layer conv tile choice, timed on this device (outside the timed region)
     from tensorflow_yolo_amd.net import dist as ydist
+
+    # The roofline figures price a kernel by the duration of a whole-batch launch that has the chip to itself: when the timed engine
+    # runs the batch as parts on several streams, a second engine of the same weights with streams = 1 serves the instrumented
+    # passes (rank 0) -- and, at N = 1, one-stream comparison legs of the same K steps BEFORE and AFTER the timed region.
+    def one_stream_engine():
+        m1 = type(model)()
+        m1.build(anchors, ["c%d" % i for i in range(ncls)], (size, size, 3), dtype=dtype, max_batch=batch, weights=w, streams=1,
+                 max_boxes=args.max_boxes, force_tile=args.force_tile)
+        return m1.net.engine
+
+    eng1 = eng
+    if world == 1 and eng.num_streams > 1:          # (N > 1: rank 0 builds it after the timed region, nothing beside the ranks' steps)
+        eng1 = one_stream_engine()
+    one_stream = None
+    legs = world == 1 and eng1 is not eng and not args.no_one_stream_leg
+    if legs:
+        one_stream = [timed_steps(eng1, xs, args.steps, args.warmup, args.threshold, args.iou_threshold)]
 
     def step(i):
         # forward + decode + NMS of this rank's images (one C call) and, for N > 1, the path's only exchange: ONE all-gather
         # of the fixed-size record buffer (rank order == image order) -- the same function the gloo CPU tests drive
         return ydist.detect_sharded(eng, xs[i & 1], args.threshold, args.iou_threshold)
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        boxes, counts, status = step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, (boxes, counts, status) = timed_region(step, args.steps, args.warmup, world, torch.cuda.synchronize, dev)
     st = status.cpu().numpy()
     nboxes = counts.cpu().numpy()
     if st.any():
         raise RuntimeError("candidate / box-record capacity exceeded during the benchmark: result would not match the reference")
+    if legs:
+        one_stream.append(timed_steps(eng1, xs, args.steps, 0, args.threshold, args.iou_threshold))
 
     out = None
     if rank == 0:
+        if eng1 is eng and eng.num_streams > 1:
+            eng1 = one_stream_engine()
         total_images = args.steps * batch * world
-        value = total_images / elapsed
-        # ---- roofline of the dominant kernel family, instrumented steps (hipEvents on the launch stream)
-        infos = eng.kernel_infos()
+        # ---- roofline of the dominant kernel family, instrumented steps (hipEvents on the launch stream), one-stream engine
+        infos = eng1.kernel_infos()
         reps = max(3, min(10, args.steps))
-        ms = np.zeros(eng.num_kernels, dtype=np.float64)
+        ms = np.zeros(eng1.num_kernels, dtype=np.float64)
         for r in range(reps):
-            ms += eng.forward_timed(xs[r & 1])
+            ms += eng1.forward_timed(xs[r & 1])
         ms /= reps
         fam = {}
         for k, ki in enumerate(infos):
@@ -286,7 +372,18 @@ def main():
                 "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
                 "algorithmic_mb_per_launch": round(d["bytes"] / d["launches"] / 1e6, 3),
                 "forward_ms_sum_of_kernels": round(float(ms.sum()), 4),
-                "whole_forward_tflops": round(eng.flops_per_image * batch / (float(ms.sum()) * 1e-3) / 1e12, 2)}
+                "whole_forward_tflops": round(eng1.flops_per_image * batch / (float(ms.sum()) * 1e-3) / 1e12, 2),
+                "measured_on": "whole-batch launches, one stream, each kernel alone on the chip (instrumented passes of %s; the same launches "
+                               "`bench.py --streams 1` times and profiles/*kernel_stats*.csv hold)" %
+                               ("the timed engine" if eng1 is eng else "a streams = 1 engine of the same weights")}
+        pk = os.path.join(ROOT, "profiles", "r04_peaks.json")      # measured ceilings of this chip family (tools/probes/peak_probe.hip)
+        if os.path.exists(pk):
+            try:
+                pj = json.load(open(pk))
+                roof["sustained_peak"] = pj["mfma_f16_tflops_sustained"] if dtype == "fp16" else pj.get("mfma_f32_tflops_sustained")
+                roof["sustained_peak_note"] = pj.get("note")
+            except Exception:
+                pass
         tj = os.path.join(ROOT, "profiles", "traffic.json")      # HBM bytes per launch from rocprofv3 --pmc passes, if recorded
         if os.path.exists(tj):
             try:
@@ -305,32 +402,34 @@ def main():
                     for k, ki in enumerate(infos)]
             with open(args.dump_kernels, "w") as f:
                 json.dump({"workload": args.workload, "families": fam, "kernels": rows}, f, indent=1)
-        out = {
-            "metric": "images/sec at 1/2/4/8 MI355X + post-NMS box-set match vs CPU ref",
-            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16" if dtype == "fp16" else "f32", "data": "synthetic",
+        out = contract_fields(rank, world, args.steps, args.warmup, batch, elapsed, dtype)
+        out.update({
             "config": {"workload": args.workload, "network": kind, "input": [size, size, 3], "batch_per_gpu": batch,
                        "global_batch": batch * world, "weights": "seeded synthetic Darknet stream (random-init)",
-                       "threshold": args.threshold, "iou_threshold": args.iou_threshold, "streams": max(1, args.streams),
+                       "threshold": args.threshold, "iou_threshold": args.iou_threshold, "streams": int(eng.num_streams),
+                       "streams_rule": "explicit --streams %d" % args.streams if args.streams > 0 else
+                                       "yolo_net_options.streams = 0: the library's rule (DESIGN.md, Kernel boundaries)",
                        "sharding": "images over ranks; all-gather of box records only" if world > 1 else "single GPU",
                        "boxes_per_image_last_step": round(float(nboxes.mean()), 1),
                        "forward_gflop_per_image": round(eng.flops_per_image / 1e9, 3)},
             "roofline": roof,
             "forward_frac_of_mfma_peak": round(eng.flops_per_image * total_images / elapsed / 1e12 / (PEAK[dtype] * world), 4),
-        }
-        if world == 1 and args.streams == 0 and batch >= 2 and not args.no_two_stream_leg:
-            out["two_streams"] = two_stream_leg(kind, size, batch, dtype, w, xs, args)
+        })
+        if legs:
+            dt1 = 0.5 * (one_stream[0] + one_stream[1])
+            out["one_stream"] = {"streams": 1, "value": round(args.steps * batch / dt1, 2), "unit": "images/sec", "ms_per_step": round(dt1 / args.steps * 1e3, 4),
+                                 "ms_per_step_before_after": [round(one_stream[0] / args.steps * 1e3, 4), round(one_stream[1] / args.steps * 1e3, 4)],
+                                 "note": "same build, weights, inputs and K steps on ONE stream, timed right before and right after the timed "
+                                         "region (A / timed / A); `value` above is the %d-stream run" % eng.num_streams}
         out["cpu_baseline"] = out["parity"] = None
-        # the CPU baseline is timed on rank 0 at N = 1 only (bench contract); the parity check (rank 0's engine, two images,
-        # outside the timed region, before the process group goes away) runs at every N
+        # the CPU baseline is timed on rank 0 at N = 1 only (bench contract); the parity check (rank 0's TIMED engine, every image of
+        # its first batch, outside the timed region, before the process group goes away) runs at every N
         time_cpu = world == 1 and not args.no_cpu_baseline
         if time_cpu or not args.no_parity:
-            base, xb, ref_logits = cpu_baseline(kind, size, w, anchors, ncls, time_it=time_cpu)
+            base, ref_logits, e_ref = cpu_baseline(kind, size, w, anchors, ncls, xs_host[0], dtype, time_it=time_cpu)
             out["cpu_baseline"] = base
             if not args.no_parity:
-                nb = min(batch, xb.shape[0])        # (a batch-1 workload checks one image)
-                out["parity"] = parity_report(model, kind, size, anchors, ncls, xb[:nb], ref_logits[:nb], args.threshold, args.iou_threshold)
+                out["parity"] = parity_report(eng, kind, size, anchors, ncls, xs[0], ref_logits, args.threshold, args.iou_threshold, dtype, e_ref)
         if world > 1:
             out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": 0, "kind": "port",
                                    "sample": "not timed at N > 1: the CPU baseline is a property of the host, see the N = 1 line"}

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define YOLO_HIP_ABI_VERSION 2      /* 2: yolo_kernel_info.symbol */
+#define YOLO_HIP_ABI_VERSION 3      /* 2: yolo_kernel_info.symbol; 3: yolo_net_num_streams, streams = 0 is the library's rule */
 
 enum yolo_status {
     YOLO_OK = 0,
@@ -86,9 +86,12 @@ typedef struct yolo_net_options {
                              * 4096 sort + NMS run in LDS, up to 65536 on global-memory slabs; an image
                              * with at most 512 candidates always takes the single-wave LDS path)    */
     int32_t max_boxes;      /* records per image written by detect / decode_nms (0 -> 256)     */
-    int32_t streams;        /* 0/1: one pass on the caller's stream; 2..4: the batch runs as that many independent
-                             * parts on the caller's + internal streams (overlaps the kernels' tails; the
-                             * environment variable YOLO_STREAMS sets the default when this is 0)          */
+    int32_t streams;        /* 1: one pass on the caller's stream; 2..4: the batch runs as that many independent
+                             * parts on the caller's + internal streams (overlaps the kernels' tails and launch
+                             * boundaries); 0: the library's rule (two parts for fp16 nets of >= 40 conv launches
+                             * whose half batch is >= 2.5 M input pixels, e.g. YOLOv3-608 at batch >= 16, else one;
+                             * the environment variable YOLO_STREAMS overrides the rule).  Results do not depend on it.
+                             * yolo_net_num_streams() tells what a net runs with.                              */
     int32_t force_tile;     /* 0: per-layer tile choice (cost model / autotune); t + 1: run conv tile id t on every
                              * conv layer that accepts it (0 = 4-wave kernel, 1-7 and 14 LDS-DMA tiles, 8-13 and 15-17
                              * tap-reuse tiles): test and tuning hook, any value gives the same results up to summation order   */
@@ -131,6 +134,7 @@ int yolo_net_head_desc(const yolo_net *net, yolo_head_desc *out);
  * net/v2.py:83-85) get their head geometry from the caller before detect() */
 int yolo_net_set_head(yolo_net *net, const yolo_head_desc *head);
 int yolo_net_num_kernels(const yolo_net *net);
+int yolo_net_num_streams(const yolo_net *net);      /* parts / HIP streams a full batch runs as (yolo_net_options.streams)   */
 /* human-readable plan (kernels, fusions, buffers); returns bytes needed incl. NUL */
 size_t yolo_net_describe(const yolo_net *net, char *buf, size_t cap);
 

@@ -10,7 +10,10 @@ v2, net/layers.py:131 for v3); class_idx is an integer.
 
 For speed the scan is pre-filtered with a vectorised pass at a slightly relaxed
 threshold; every surviving cell is then recomputed with the reference's scalar
-expressions, and the reference's own `p < threshold` test decides.
+expressions, and the reference's own `p < threshold` test decides.  `full_scan=True`
+walks EVERY cell with the scalar expressions instead, the way the reference's triple
+loop does (net/v2.py:98-100, net/v3.py:113-115): same result, the reference's cost --
+bench.py times it as the CPU decode baseline.
 """
 import numpy as np
 
@@ -68,19 +71,22 @@ def non_maximum_suppression(boxes, iou_threshold):   # base.py:195-209
     return kept
 
 
-def _decode_cells(out, anchors, threshold, version, scan_base=0):
+def _decode_cells(out, anchors, threshold, version, scan_base=0, full_scan=False):
     """out: [h, w, A, 5+C] float32.  anchors: sequence of (aw, ah) np.float64 in grid units.
     Returns boxes in the reference scan order (cy, cw, anchor)."""
     with np.errstate(over="ignore"):
         h, w, A = out.shape[0:3]
-        po_all = sigmoid(out[..., 4])
-        if version == 2:
-            cls = out[..., 5:]
-            e = np.exp(cls - cls.max(axis=-1, keepdims=True))
-            p_all = po_all * (e.max(axis=-1) / e.sum(axis=-1))
+        if full_scan:
+            cand = ((cy, cw, b) for cy in range(h) for cw in range(w) for b in range(A))     # v2.py:98-100 / v3.py:113-115
         else:
-            p_all = po_all
-        cand = np.argwhere(p_all >= threshold - _RELAX)         # row-major == scan order
+            po_all = sigmoid(out[..., 4])
+            if version == 2:
+                cls = out[..., 5:]
+                e = np.exp(cls - cls.max(axis=-1, keepdims=True))
+                p_all = po_all * (e.max(axis=-1) / e.sum(axis=-1))
+            else:
+                p_all = po_all
+            cand = np.argwhere(p_all >= threshold - _RELAX)         # row-major == scan order
         boxes = []
         for cy, cw, b in cand:
             prob_obj = sigmoid(out[cy, cw, b, 4])
@@ -105,14 +111,14 @@ def _decode_cells(out, anchors, threshold, version, scan_base=0):
         return boxes
 
 
-def find_bounding_boxes_v2(net_out, threshold, iou_threshold, anchors, num_classes, nms=True):
+def find_bounding_boxes_v2(net_out, threshold, iou_threshold, anchors, num_classes, nms=True, full_scan=False):
     """net/v2.py:83-90.  net_out: [B,h,w,A*(5+C)] float32; anchors [A,2] in grid units."""
     anchors = np.reshape(np.asarray(anchors, np.float64), [-1, 2])
     net_out = np.asarray(net_out, np.float32)
     net_out = np.reshape(net_out, [-1, net_out.shape[1], net_out.shape[2], len(anchors), 5 + num_classes])
     res = []
     for out in net_out:
-        boxes = _decode_cells(out, anchors, threshold, 2)
+        boxes = _decode_cells(out, anchors, threshold, 2, full_scan=full_scan)
         res.append(non_maximum_suppression(boxes, iou_threshold) if nms else boxes)
     return res
 
@@ -128,7 +134,7 @@ def v3_scales(anchors_px, input_hw, strides=(32, 16, 8)):
     return out
 
 
-def find_bounding_boxes_v3(net_out, threshold, iou_threshold, scales, nms=True):
+def find_bounding_boxes_v3(net_out, threshold, iou_threshold, scales, nms=True, full_scan=False):
     """net/v3.py:140-151.  net_out: [B, sum(h*w*b), 5+C] float32; scales from v3_scales()."""
     net_out = np.asarray(net_out, np.float32)
     res = []
@@ -138,7 +144,7 @@ def find_bounding_boxes_v3(net_out, threshold, iou_threshold, scales, nms=True):
         for (h, w, anc) in scales:
             dim = h * w * len(anc)
             l_out = np.reshape(out[idx:idx + dim, ...], [h, w, len(anc), -1])
-            boxes.extend(_decode_cells(l_out, anc, threshold, 3, scan_base=idx))
+            boxes.extend(_decode_cells(l_out, anc, threshold, 3, scan_base=idx, full_scan=full_scan))
             idx += dim
         res.append(non_maximum_suppression(boxes, iou_threshold) if nms else boxes)
     return res

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enum yolo_op
 OP_INPUT, OP_CONV, OP_MAXPOOL, OP_ROUTE, OP_REORG, OP_SHORTCUT, OP_UPSAMPLE, OP_YOLO, OP_DETECTION = range(9)
@@ -66,6 +66,7 @@ SIGNATURES = {
     "yolo_net_head_desc": (C.c_int, [C.c_void_p, C.POINTER(HeadDesc)]),
     "yolo_net_set_head": (C.c_int, [C.c_void_p, C.POINTER(HeadDesc)]),
     "yolo_net_num_kernels": (C.c_int, [C.c_void_p]),
+    "yolo_net_num_streams": (C.c_int, [C.c_void_p]),
     "yolo_net_describe": (C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "yolo_net_load_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "yolo_net_bind_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -28,6 +28,18 @@ namespace {
 const size_t kPairCounterBytes = 16384;            // in-launch pair split (conv_tap.hip): one int per tile, in front of the slabs
 bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile);
 size_t splitk_slab_bytes(const yolo_net *net);
+
+// Ticket counters of the in-launch pair split: every launch returns them to zero, so they are cleared when the workspace is bound
+// and again after any failed forward (a launch that did not run may leave the forward half-way).  The memset goes to the null
+// stream, which does not order against the non-blocking streams a caller may launch on: hence the device-wide synchronise.
+int zero_pair_counters(yolo_net *net) {
+    if (!net->splitk_bytes || !net->dev_ws) return YOLO_OK;
+    const size_t per = net->splitk_bytes / (size_t)net->arenas;
+    for (int a = 0; a < net->arenas; ++a)
+        HIP_TRY(hipMemset(net->dev_ws + net->splitk_off + (size_t)a * (per / 256 * 256), 0, per < kPairCounterBytes ? per : kPairCounterBytes));
+    HIP_TRY(hipDeviceSynchronize());
+    return YOLO_OK;
+}
 }
 
 extern "C" {
@@ -83,6 +95,7 @@ size_t yolo_net_workspace_bytes(const yolo_net *net) { return net ? net->workspa
 size_t yolo_net_output_count(const yolo_net *net) { return net ? net->out_count : 0; }
 double yolo_net_flops_per_image(const yolo_net *net) { return net ? net->flops_per_image : 0.0; }
 int yolo_net_num_kernels(const yolo_net *net) { return net ? (int)net->kernels.size() : 0; }
+int yolo_net_num_streams(const yolo_net *net) { return net ? net->arenas : 0; }
 
 int yolo_net_head_desc(const yolo_net *net, yolo_head_desc *out) {
     if (!net || !out) return fail(YOLO_ERR_ARG, "yolo_net_head_desc: null argument");
@@ -142,10 +155,8 @@ int yolo_net_bind_workspace(yolo_net *net, void *ws, size_t bytes) {
     if ((uintptr_t)ws % 256) return fail(YOLO_ERR_ARG, "yolo_net_bind_workspace: workspace must be 256-byte aligned");
     net->dev_ws = static_cast<unsigned char *>(ws);
     net->dev_ws_bytes = bytes;
-    if (net->splitk_bytes)      // ticket counters of the in-launch pair split (every launch returns them to zero)
-        for (int a = 0; a < net->arenas; ++a)
-            HIP_TRY(hipMemset(net->dev_ws + net->splitk_off + (size_t)a * (net->splitk_bytes / (size_t)net->arenas / 256 * 256), 0,
-                              net->splitk_bytes / (size_t)net->arenas < kPairCounterBytes ? net->splitk_bytes / (size_t)net->arenas : kPairCounterBytes));
+    int rc = zero_pair_counters(net);
+    if (rc) return rc;
     return YOLO_OK;
 }
 
@@ -321,7 +332,8 @@ ConvPick pick_conv(const yolo_net *net, const Kernel &k, const ConvParams &p, in
     // two co-resident half-K workgroups per tile, the second arriver sums -- no reduce kernel, 2 x 64 KiB of slab per tile.
     int pair = 0;
     static const bool no_pair = getenv("YOLO_NO_PAIR_SPLIT") != nullptr;       // A/B switch (read once; results unchanged up to summation order)
-    if (ks <= 1 && tile > 0 && dma_cfg_is_tap(tile) && !no_pair) {
+    // (an explicitly requested tile -- force_tile, an autotune candidate -- runs as requested: the hook must time and test the tile it names)
+    if (ks <= 1 && tile > 0 && dma_cfg_is_tap(tile) && !no_pair && tile_req <= 0) {
         const long long mq = (long long)(p.M / p.HoWo) * (p.H + 1) * (p.W + 1);
         const int units = p.cin_chunks >> 2;
         const long long ct = (p.Cout + 127) / 128;
@@ -531,7 +543,18 @@ int run_forward_pass(yolo_net *net, const float *in_dev, int batch, float *out_d
 // ones, fork/join by events): images are independent, so the ragged tail + cold start of every kernel of one part overlaps
 // the bulk of the other parts' kernels instead of leaving CUs idle at each of the ~73 kernel boundaries.  Every part has
 // its own activation arena (plan.cpp: allocate).
+int run_forward_impl(yolo_net *net, const float *in_dev, int batch, float *out_dev, hipStream_t s, hipEvent_t *ev);
 int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, hipStream_t s, hipEvent_t *ev = nullptr) {
+    const int rc = run_forward_impl(net, in_dev, batch, out_dev, s, ev);
+    if (rc != YOLO_OK) {        // leave the pair-split counters as every later launch expects them; keep the first error's message
+        const std::string msg = get_error();
+        (void)hipGetLastError();
+        (void)zero_pair_counters(net);
+        set_error(msg);
+    }
+    return rc;
+}
+int run_forward_impl(yolo_net *net, const float *in_dev, int batch, float *out_dev, hipStream_t s, hipEvent_t *ev) {
     const long long rows = net->head.n_classes > 0 ? (long long)(net->out_count / (size_t)(5 + net->head.n_classes)) : -1;
     const int parts = net->arenas;
     const int per = (net->opt.max_batch + parts - 1) / parts;       // images an arena holds
@@ -668,6 +691,7 @@ int yolo_net_forward_timed(yolo_net *net, const float *in_dev, int batch, float 
     }
     net->obj_valid = false;     // (the timed pass is not followed by a decode)
     (void)rows_written;
+    if (rc != YOLO_OK) { const std::string msg = get_error(); (void)hipGetLastError(); (void)zero_pair_counters(net); set_error(msg); }
     for (auto &e : ev) (void)hipEventDestroy(e);
     return rc;
 }

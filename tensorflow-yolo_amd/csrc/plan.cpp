@@ -383,7 +383,9 @@ struct Planner {
                 wsrc += (size_t)d.filters * cin * taps + (d.batch_norm ? 4 : 1) * (size_t)d.filters;
                 k.w_off = woff; k.w_bytes = wrow * cout_pad;
                 k.b_off = roundup_sz(k.w_off + k.w_bytes, 256);
-                woff = roundup_sz(k.b_off + (size_t)cout_pad * 4, 256);
+                // (bias region padded to a multiple of 256 couts: the 256-cout tiles load the bias of their whole tile as the
+                // accumulators' initial value before they know how many of its couts exist -- conv_common.h: conv_init_acc_bias)
+                woff = roundup_sz(k.b_off + (size_t)roundup(d.filters, 256) * 4, 256);
                 flops += 2.0 * L[i].H * L[i].W * d.filters * taps * cin;
                 // Darknet-53 stem: first-layer kernel + this 3x3/2 32->64 conv as one kernel (stem.hip) when nobody else
                 // reads the 32-channel tensor (keep_all needs it in memory) and the output takes 16-byte stores
@@ -572,8 +574,20 @@ struct Planner {
         // Multi-stream forward (yolo_net_options.streams / YOLO_STREAMS): the batch runs as independent parts, each in its
         // own arena planned for its share of the batch -- lifetime-based reuse packs tensors of different per-image size into the same
         // bytes, so two halves at different layers must not share an arena.  Same total memory.
+        // streams = 0 is the library's own rule, from interleaved one-stream / two-stream runs on one box (profiles/r04_streams_ab.jsonl):
+        // two parts win where a half batch still fills the chip at every layer AND the net is a long chain of short launches
+        // (YOLOv3-608 b32 +4.5 %, b16 +4.6 %, YOLOv3-416 b32 +5.8 %), lose where the halves get small (YOLOv3-416 b16 -4.5 %,
+        // YOLOv3-608 b8 -5 %, YOLOv2-416 b16 -18 %) and do nothing for the short Darknet-19 chains (YOLOv2-416 b32 / b64 +-0.3 %,
+        // tiny-YOLOv2 b64 float32 -0.5 %): fp16, >= 40 conv launches, >= 2.5 M input pixels per part.
         {
-            const int want = net->opt.streams > 0 ? net->opt.streams : (getenv("YOLO_STREAMS") ? atoi(getenv("YOLO_STREAMS")) : 1);
+            int want = net->opt.streams > 0 ? net->opt.streams : (getenv("YOLO_STREAMS") ? atoi(getenv("YOLO_STREAMS")) : 0);
+            if (want <= 0) {
+                int convs = 0;
+                for (const Kernel &k : K) convs += k.kind == K_CONV && k.stem < 3;
+                const yolo_layer_desc &d0 = net->layers[0].d;
+                const double px_per_part = (double)(net->opt.max_batch / 2) * d0.h * d0.w;
+                want = (net->opt.dtype == YOLO_DTYPE_F16 && convs >= 40 && px_per_part >= 2.5e6) ? 2 : 1;
+            }
             net->arenas = (want >= 2 && !net->opt.keep_all) ? (want > 4 ? 4 : want) : 1;
             if (net->arenas > net->opt.max_batch) net->arenas = net->opt.max_batch;
         }

@@ -97,6 +97,7 @@ class Plan(object):
         self.output_count = self.lib.yolo_net_output_count(handle)
         self.flops_per_image = self.lib.yolo_net_flops_per_image(handle)
         self.num_kernels = self.lib.yolo_net_num_kernels(handle)
+        self.num_streams = self.lib.yolo_net_num_streams(handle)       # parts a full batch runs as (streams=0: the library's rule)
         self.input_hwc = self.layers[0].out.hwc
         last = self.layers[-1]
         if isinstance(last, L.detection_layer):

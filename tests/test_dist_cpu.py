@@ -127,6 +127,54 @@ def test_sharded_step_world2_gloo():
         assert calls == (3 if rank == 0 else 2)                         # rank 1 ran no kernels for the 1-image batch
 
 
+def _bench_worker(rank, world, port, q):
+    """bench.py's own timed region and contract line under two gloo ranks (the stand-in engine in place of the HIP one)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, ROOT)
+        import bench
+        eng = StandInEngine(max_batch=3, max_boxes=6)
+        xs = [torch.stack([torch.full((4, 4, 3), t) for t in TAGS[:3]]), torch.stack([torch.full((4, 4, 3), t) for t in TAGS[2:5]])]
+        seen = []
+
+        def step(i):
+            seen.append(i)
+            return ydist.detect_sharded(eng, xs[i & 1], 0.5, 0.6)
+
+        elapsed, (boxes, counts, status) = bench.timed_region(step, 4, 2, world, lambda: None, torch.device("cpu"))
+        line = bench.contract_fields(rank, world, 4, 2, 3, elapsed, "fp16")
+        q.put((rank, elapsed, seen, tuple(boxes.shape), line))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_timed_region_and_contract_line_world2_gloo():
+    """The N > 1 half of the bench contract on CPU: W untimed + exactly K timed steps per rank, ONE time for the job (the MAX over
+    ranks, equal on both), rank 0 alone gets a line -- with n_gpus = 2 and the whole-job images/sec -- and no other rank does
+    (so `parity` / `cpu_baseline`, which bench.py hangs on that line, exist on rank 0 only)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (r0, e0, seen0, shape0, line0), (r1, e1, seen1, shape1, line1) = got
+    assert e0 == e1 > 0                                  # max over ranks: one number for the job
+    assert seen0 == seen1 == [0, 1, 0, 1, 2, 3]          # 2 warm-up + exactly 4 timed steps on every rank
+    assert shape0 == shape1 == (2, 3, 6, 6)              # every step ended in the all-gather of both shards
+    assert line1 is None                                 # rank 1 prints nothing: no line, hence no parity / cpu_baseline of its own
+    assert line0["n_gpus"] == 2 and line0["steps"] == 4 and line0["warmup"] == 2 and line0["scaling"] == "weak"
+    assert line0["value"] == round(4 * 3 * 2 / e0, 2) and line0["unit"] == "images/sec" and line0["vs_baseline"] is None
+    assert "parity" not in line0 and "cpu_baseline" not in line0      # (added by main() on rank 0 only, after the timed region)
+
+
 def test_single_process_is_identity():
     eng = StandInEngine(max_batch=2, max_boxes=4)
     x = torch.stack([torch.full((2, 2, 3), 0.25), torch.full((2, 2, 3), 0.5)])

@@ -50,9 +50,12 @@ def test_logits_fp16_bounded(kind, size, batch):
           % (kind, size, batch, e16, e32, np.abs(want32).max()))
     # fp16 rounding noise decorrelates through tens of layers; the emulation differs only in fp32 summation order
     assert e16 <= 2e-2, e16
-    # absolute, near the measured behaviour (0.013 ... 0.036 on logits of up to +-23 through 23 / 75 fp16 layers): a bound
-    # relative to max|logit| would let 3.5 pass
-    assert e32 <= 0.1, e32
+    # distance to the fp32 reference: bounded by what fp16 STORAGE alone does to these logits according to the oracle
+    # (e_ref, independent of the HIP path; measured 0.013 ... 0.036 on logits of up to +-23 through 23 / 75 fp16 layers) --
+    # the HIP path and the emulation are two realisations of the same rounding noise, 1.5 covers the spread of the maximum
+    e_ref = float(np.max(np.abs(want16.astype(np.float64) - want32)))
+    print("   e_ref %.3e  e_hip / e_ref %.2f" % (e_ref, e32 / e_ref))
+    assert e32 <= 1.5 * e_ref, (e32, e_ref)
 
 
 def test_known_answer_sizes_from_the_library():
@@ -141,7 +144,9 @@ def test_multi_stream_forward_and_detect(streams):
     recs_b, st = E.records_to_host(*many.detect(x, 0.3, 0.5))
     assert not st.any()
     sc = decode_ref.v3_scales(cases.COCO_V3_ANCHORS, (160, 160))
-    rep = parity.check(a, b, recs_b, 3, 0.3, 0.5, scales=sc)           # reference here = the single-pass logits
+    L = to_oracle(net)
+    e_ref = float(np.max(np.abs(FR.forward(L, w, x, storage="fp16").astype(np.float64) - FR.forward(L, w, x))))
+    rep = parity.check(a, b, recs_b, 3, 0.3, 0.5, scales=sc, e_ref=e_ref)           # reference here = the single-pass logits
     want = decode_ref.find_bounding_boxes_v3(a, 0.3, 0.5, sc)
     for i in range(6):                                                  # the single pass itself is exact against its own logits
         from helpers import match_boxes
@@ -186,8 +191,9 @@ def test_config2_v2_416_batch16_fp16_full_size():
     got = model.forward(x)
     e16 = rel_err(got, want16)
     boxes = model.predict(x, 0.5, 0.6)
+    e_ref = float(np.max(np.abs(want16.astype(np.float64) - want32)))
     rep = parity.check(want32, got, [[(b.x, b.y, b.w, b.h, b.class_idx, b.prob) for b in img] for img in boxes], 2, 0.5, 0.6,
-                       anchors=cases.COCO_V2_ANCHORS, num_classes=80)
+                       anchors=cases.COCO_V2_ANCHORS, num_classes=80, e_ref=e_ref)
     print("v2-416 b16 fp16: rel vs fp16-emulating oracle %.2e; vs fp32 oracle: %s" % (e16, rep))
     names = " ".join(ki.name.decode() for ki in model.net.engine.kernel_infos())
     print(names)
@@ -216,7 +222,7 @@ def test_config5_tiny_v2_voc_batch64_fp32_full_size():
     got = model.forward(x)
     boxes = model.predict(x, 0.5, 0.6)
     rep = parity.check(want, got, [[(b.x, b.y, b.w, b.h, b.class_idx, b.prob) for b in img] for img in boxes], 2, 0.5, 0.6,
-                       anchors=cases.VOC_TINY_ANCHORS, num_classes=20)
+                       anchors=cases.VOC_TINY_ANCHORS, num_classes=20, abs_bound=1e-4)
     print("tiny-v2-voc b64 fp32:", rep)
     assert rep["max_abs_logit_err"] <= 1e-4, rep
     parity.assert_ok(rep)
@@ -240,12 +246,15 @@ def test_v3_608_fp32_within_1e4_and_fp16_boxes_vs_fp32_oracle():
     t = _oracle_threads()
     try:
         want = FR.forward(to_oracle(net), w, x)
+        want16 = FR.forward(to_oracle(net), w, x, storage="fp16")
     finally:
         torch.set_num_threads(t)
+    e_ref = float(np.max(np.abs(want16.astype(np.float64) - want)))
     sc = decode_ref.v3_scales(cases.COCO_V3_ANCHORS, (608, 608))
     got32 = m32.forward(x)
     b32 = m32.predict(x, 0.5, 0.6)
-    rep32 = parity.check(want, got32, [[(b.x, b.y, b.w, b.h, b.class_idx, b.prob) for b in img] for img in b32], 3, 0.5, 0.6, scales=sc)
+    rep32 = parity.check(want, got32, [[(b.x, b.y, b.w, b.h, b.class_idx, b.prob) for b in img] for img in b32], 3, 0.5, 0.6, scales=sc,
+                         abs_bound=1e-4)
     print("v3-608 b2 fp32: max|logit| %.2f  %s" % (float(np.abs(want).max()), rep32))
     assert rep32["max_abs_logit_err"] <= 1e-4, rep32
     parity.assert_ok(rep32)
@@ -253,6 +262,51 @@ def test_v3_608_fp32_within_1e4_and_fp16_boxes_vs_fp32_oracle():
     m16.build(cases.COCO_V3_ANCHORS, NAMES80, (608, 608, 3), dtype="fp16", max_batch=2, weights=w)
     got16 = m16.forward(x)
     b16 = m16.predict(x, 0.5, 0.6)
-    rep16 = parity.check(want, got16, [[(b.x, b.y, b.w, b.h, b.class_idx, b.prob) for b in img] for img in b16], 3, 0.5, 0.6, scales=sc)
+    rep16 = parity.check(want, got16, [[(b.x, b.y, b.w, b.h, b.class_idx, b.prob) for b in img] for img in b16], 3, 0.5, 0.6, scales=sc,
+                         e_ref=e_ref)
     print("v3-608 b2 fp16 vs the fp32 oracle pipeline:", rep16)
     parity.assert_ok(rep16)
+
+
+def test_v3_608_b32_distinct_images_vs_oracle():
+    """The plan `bench.py` times (BASELINE.json configs[2]: YOLOv3 608x608, batch 32, fp16, default options -- two half batches
+    on two HIP streams by the library's rule) on 32 DISTINCT images: tile choice depends on M = B Ho Wo (pair split-K, the
+    256 x 224 tile at 19 x 19, the 2-D tiles at 152 x 152 are batch-dependent), so batch 2 proves nothing about these launches.
+    Every image's logits against the fp32 oracle within 1.5 x e_ref (e_ref = what fp16 storage does to them per the oracle) and
+    against the fp16-emulating oracle; the post-NMS boxes of all 32 against the fp32 oracle pipeline under the gate."""
+    import torch
+    from oracle import decode_ref, parity
+    from tensorflow_yolo_amd import YoloV3
+    net, nc = build("v3", 608)
+    hg, frac = synth.HEAD_DEFAULTS["v3"]
+    w = synth.darknet_stream(net, seed=5, num_classes=nc, head_gain=hg, obj_bias=0.0)
+    x = synth.synthetic_input(32, 608, 608, 3, seed=31)
+    assert len({x[i].tobytes()[:4096] for i in range(32)}) == 32
+    m = YoloV3()
+    m.build(cases.COCO_V3_ANCHORS, NAMES80, (608, 608, 3), dtype="fp16", max_batch=32, weights=w)
+    w = synth.calibrate_model(m, x, frac)
+    eng = m.net.engine
+    assert eng.num_streams == 2, "the headline plan runs as two half batches (yolo_net_options.streams = 0: the library's rule)"
+    L = to_oracle(net)
+    t = _oracle_threads()
+    try:
+        want, want16 = [], []
+        for i in range(0, 32, 4):           # (chunks bound the oracle's activation memory)
+            want.append(FR.forward(L, w, x[i:i + 4]))
+            want16.append(FR.forward(L, w, x[i:i + 4], storage="fp16"))
+    finally:
+        torch.set_num_threads(t)
+    want, want16 = np.concatenate(want), np.concatenate(want16)
+    e_ref = float(np.max(np.abs(want16.astype(np.float64) - want)))
+    got = m.forward(x)
+    per_image = np.max(np.abs(got.astype(np.float64) - want).reshape(32, -1), axis=1)
+    e16 = rel_err(got, want16)
+    boxes = m.predict(x, 0.5, 0.6)
+    sc = decode_ref.v3_scales(cases.COCO_V3_ANCHORS, (608, 608))
+    rep = parity.check(want, got, [[(b.x, b.y, b.w, b.h, b.class_idx, b.prob) for b in img] for img in boxes], 3, 0.5, 0.6, scales=sc,
+                       e_ref=e_ref)
+    print("v3-608 b32 fp16, 32 distinct images on the timed plan: e_ref %.3e, per-image max|err| %.3e .. %.3e, rel vs fp16 emulation %.2e; %s"
+          % (e_ref, per_image.min(), per_image.max(), e16, {k: v for k, v in rep.items() if k != "unexplained_notes"}))
+    assert rep["images_checked"] == 32 and rep["boxes_ref"] > 500
+    assert e16 <= 2e-2, e16
+    parity.assert_ok(rep)

@@ -205,14 +205,16 @@ def test_conv_maxpool_fused_32_cout_tile(dtype):
     assert "32x256,tap9,2d,x2>" in " ".join(ki.name.decode() for ki in eng2.kernel_infos())
 
 
+@pytest.mark.parametrize("cout", [32, 16])
 @pytest.mark.parametrize("hw", [(20, 44), (32, 64), (6, 130)])
-def test_first_layer_pool_on_the_matrix_cores(hw):
-    """Darknet-19's first layer + pool in fp16 nets (conv 3x3/1 3 -> 32 + BN + leaky + 2x2/2 max-pool): first_pool_mfma_kernel
-    (8 x 16 pooled-output tiles, partial tiles in both directions, image borders = zero padding, several images) against the
-    oracle through a following conv; the float32 net keeps the direct VALU kernel (same check)"""
+def test_first_layer_pool_on_the_matrix_cores(hw, cout):
+    """Darknet-19's (32 filters) / tiny-YOLOv2's (16) first layer + pool (conv 3x3/1 3 -> cout + BN + leaky + 2x2/2 max-pool) on the
+    matrix cores: fp16 nets with 32 filters run first_pool_mfma_kernel, float32 nets first_pool_mfma_f32_kernel<cout / 16>
+    (8 x 16 pooled-output tiles, partial tiles in both directions, image borders = zero padding, several images), against the
+    oracle through a following conv; an fp16 net with 16 filters keeps the direct VALU kernel (same check)"""
     H, W = hw
     g = new_graph(H, W, 3)
-    g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))
+    g.append(PL.conv2d_bn_act(g[-1].out, cout, 3, 1))
     g.append(PL.max_pool2d(g[-1].out, 2, 2))
     g.append(PL.conv2d_bn_act(g[-1].out, 64, 3, 1))
     x = synth.synthetic_input(3, H, W, 3, seed=23)
@@ -221,7 +223,12 @@ def test_first_layer_pool_on_the_matrix_cores(hw):
         names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
         syms = " ".join(ki.symbol.decode() for ki in eng.kernel_infos())
         assert "conv_first_pool" in names and eng.num_kernels == 2, names
-        assert ("first_pool_mfma_kernel" in syms) == (dtype == "fp16"), syms
+        if dtype == "fp32":
+            assert "first_pool_mfma_f32_kernel<%d>(" % (cout // 16) in syms, syms
+        elif cout == 32:
+            assert "yolo::first_pool_mfma_kernel(" in syms, syms
+        else:
+            assert "conv_first_kernel<false, 16, true>" in syms, syms
 
 
 def test_variable_batch_below_max_batch():
@@ -407,6 +414,40 @@ def test_every_dma_tile_config(tile):
     eng = check_graph(g, x, "fp16", seed=3, read=(2, 5, 7, 10), tile=tile)
     names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
     assert "conv_igemm_dma" in names
+
+
+@pytest.mark.parametrize("dtype,shape", [("fp16", (24, 13, 13, 256, 512)), ("fp16", (20, 19, 19, 512, 256)),
+                                         ("fp32", (24, 13, 13, 128, 512)), ("fp32", (24, 19, 19, 128, 256))])
+def test_in_launch_pair_split_k(dtype, shape):
+    """The K split INSIDE one launch (conv_tap.hip: two half-K workgroups per tile hand their accumulators over through write-through
+    slabs and a ticket, the second arriver sums and runs the fused epilogue; api.cpp: pick_conv) at op level: 13 x 13 and 19 x 19
+    maps at the batch that gives 64-128 tiles of 128 x 256 (fp16) or 129-256 tiles of 128 x 128 (float32: the only tile whose
+    float32 pair instantiation exists).  Asserted: the pair kernel is what runs; the result against the oracle (with a residual, so
+    the fused epilogue of the second arriver is the full one); bit-identical results on a second and third launch of the same engine
+    (the ticket counters return to zero); and agreement with the whole-K kernel of the same tile (an explicitly forced tile is
+    never overridden by the pair split)."""
+    B, H, W, cin, cout = shape
+    g = new_graph(H, W, cin)
+    g.append(PL.conv2d_bn_act(g[-1].out, cout, 3, 1))            # 1: the pair launch
+    g.append(PL.conv2d_bn_act(g[-1].out, cout, 3, 1))            # 2: ... and one with a residual behind it
+    g.append(PL.shortcut(g[-1].out, g[1].out))
+    x = synth.synthetic_input(B, H, W, cin, seed=77)
+    eng = check_graph(g, x, dtype, seed=12)
+    infos = eng.kernel_infos()
+    names = [ki.name.decode() for ki in infos]
+    syms = [ki.symbol.decode() for ki in infos]
+    pair = [i for i, n in enumerate(names) if "+pairK" in n]
+    assert len(pair) == 2, names
+    want_sym = "conv3x3_tap_kernel<false, 2, 4, 4, 4, 26, 2, 1, true>" if dtype == "fp16" else "conv3x3_tap_kernel<true, 2, 4, 4, 2, 28, 4, 1, true>"
+    assert all(want_sym in syms[i] for i in pair), syms
+    a = eng.forward(x).cpu().numpy()
+    b = eng.forward(x).cpu().numpy()
+    c = eng.forward(x[:B]).cpu().numpy()
+    assert np.array_equal(a, b) and np.array_equal(a, c), "the pair launch is not repeatable: a ticket counter did not return to zero"
+    tile = 8 if dtype == "fp16" else 11
+    whole, eng_w = run_hip(g, synth.darknet_stream(g, seed=12), x, dtype, force_tile=tile)
+    assert not any("+pairK" in ki.name.decode() for ki in eng_w.kernel_infos()), "a forced tile must run as it is named"
+    assert rel_err(a, whole) <= (2e-3 if dtype == "fp16" else 2e-6)        # same products, K summed in two halves
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "fp32"])

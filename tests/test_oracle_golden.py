@@ -16,18 +16,23 @@ def _load(name):
     return g, meta
 
 
+@pytest.mark.parametrize("full_scan", [False, True])
 @pytest.mark.parametrize("name", sorted(cases.CASES))
-def test_decode_matches_reference(name):
+def test_decode_matches_reference(name, full_scan):
+    """full_scan: the per-cell Python scan exactly as the reference's triple loop walks it (what bench.py times as the CPU
+    decode baseline) instead of the vectorised pre-filter -- both against the reference's own outputs"""
     c = cases.CASES[name]
+    if full_scan and c["input"] >= 608 and c["batch"] > 1:
+        pytest.skip("the full scan of the large multi-image case takes tens of seconds; the single-image 608 case covers it")
     g, meta = _load(name)
     assert meta["source"] == "reference functions"
     head = cases.make_head(name)
     for nms in (False, True):
         if c["version"] == 2:
-            mine = decode_ref.find_bounding_boxes_v2(head, c["threshold"], c["iou"], c["anchors"], c["classes"], nms=nms)
+            mine = decode_ref.find_bounding_boxes_v2(head, c["threshold"], c["iou"], c["anchors"], c["classes"], nms=nms, full_scan=full_scan)
         else:
             sc = decode_ref.v3_scales(c["anchors"], (c["input"], c["input"]))
-            mine = decode_ref.find_bounding_boxes_v3(head, c["threshold"], c["iou"], sc, nms=nms)
+            mine = decode_ref.find_bounding_boxes_v3(head, c["threshold"], c["iou"], sc, nms=nms, full_scan=full_scan)
         for i in range(c["batch"]):
             want = g[("post%d" if nms else "pre%d") % i]
             got = decode_ref.boxes_to_array(mine[i])

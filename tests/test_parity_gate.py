@@ -36,14 +36,42 @@ def test_noise_is_explained(version, noise):
     rng = np.random.RandomState(5)
     got = (head + rng.uniform(-noise, noise, size=head.shape)).astype(np.float32)
     boxes = _hip_like(c, got, kw)
-    rep = parity.check(head, got, boxes, version, c["threshold"], c["iou"], **kw)
+    # the bound the bands may use comes from OUTSIDE the path under test: here the noise amplitude stands in for 1.5 x e_ref
+    bound = dict(abs_bound=1e-4) if noise == 0.0 else dict(e_ref=noise / 1.5)
+    rep = parity.check(head, got, boxes, version, c["threshold"], c["iou"], **bound, **kw)
     assert rep["boxes_ref"] > 20
     assert rep["boxes_unexplained"] == 0, rep
+    assert rep["logit_err_within_bound"]
     parity.assert_ok(rep) if not rep["identity_required"] or rep["box_set_match"] else None
     if noise == 0.0:
         assert rep["box_set_match"] and rep["identity_required"] and rep["rows_differing"] == 0
+        assert rep["prob_flip_band"] == 0.0 and rep["iou_flip_band"] == 0.0
     if noise == 6e-2:
         assert rep["rows_differing"] > 0, "the case is too easy: no flip to explain at this noise level"
+    # the bands that explained something come from the rows' own errors: never wider than the cap the bound allows
+    assert rep["prob_flip_band"] <= rep["prob_flip_band_cap"] + 3e-7 and rep["iou_flip_band"] <= rep["iou_flip_band_cap"]
+
+
+@pytest.mark.parametrize("version", [2, 3])
+def test_a_forward_defect_cannot_widen_its_own_bands(version):
+    """Round-3 gate: dp, diou came from the HIP path's OWN max |logit error|, so a forward defect that raised the error also raised
+    the bands that should catch it.  Now: logits off by 0.09 everywhere (fp16 storage explains ~0.02 on these sizes) must FAIL,
+    although every box the perturbed logits decode to is reported faithfully (link 1 holds)."""
+    c, head, kw = _case(version)
+    rng = np.random.RandomState(11)
+    got = (head + rng.choice([-0.09, 0.09], size=head.shape)).astype(np.float32)
+    boxes = _hip_like(c, got, kw)
+    rep = parity.check(head, got, boxes, version, c["threshold"], c["iou"], e_ref=0.02, **kw)
+    assert not rep["logit_err_within_bound"] and rep["logit_err_bound"] == pytest.approx(0.03)
+    assert rep["iou_flip_band_cap"] == pytest.approx(0.12) and rep["iou_flip_band"] <= 0.12
+    assert rep["rows_differing"] > 0
+    if version == 3:            # score = sigmoid(obj): moves by up to 0.09 / 4, the band stays at 0.03 / 4 -> flips beyond it stay unexplained
+        assert rep["boxes_unexplained"] > 0, rep      # (v2's score band is e itself: |d(sigmoid * softmax-max)| < e, so 0.03 covers what 0.09 does to it)
+    with pytest.raises(AssertionError):
+        parity.assert_ok(rep)
+    # the same logits under the old rule (no independent bound: the path's own error) would have been waved through
+    old = parity.check(head, got, boxes, version, c["threshold"], c["iou"], **kw)
+    assert old["logit_err_bound_source"].startswith("none given") and old["boxes_unexplained"] == 0 and old["logit_err_within_bound"]
 
 
 @pytest.mark.parametrize("version", [2, 3])
@@ -72,10 +100,12 @@ def test_defects_are_not_explained(version, defect):
         g2[img, row, 4] -= 30.0
         got = g2.reshape(got.shape)
         boxes = _hip_like(c, got, kw)
-        rep = parity.check(head, got, boxes, version, c["threshold"], c["iou"], **kw)
-        assert rep["max_abs_logit_err"] > 1.0           # this kind shows in the logit error, which every test bounds
+        rep = parity.check(head, got, boxes, version, c["threshold"], c["iou"], e_ref=2e-2 / 1.5, **kw)
+        assert rep["max_abs_logit_err"] > 1.0 and not rep["logit_err_within_bound"]     # this kind shows in the logit error
+        with pytest.raises(AssertionError):
+            parity.assert_ok(rep)
         return
-    rep = parity.check(head, got, boxes, version, c["threshold"], c["iou"], **kw)
+    rep = parity.check(head, got, boxes, version, c["threshold"], c["iou"], e_ref=2e-2 / 1.5, **kw)
     assert rep["boxes_unexplained"] >= 1, rep
     with pytest.raises(AssertionError):
         parity.assert_ok(rep)

@@ -7,6 +7,7 @@ ROOTDIR=$(pwd)
 LIB=tensorflow-yolo_amd/libyolo_hip.so
 mkdir -p gpurun_out/ldsab
 cp $LIB /tmp/lib_a.so
+trap 'cp /tmp/lib_a.so "$ROOTDIR/$LIB"' EXIT      # the tree build comes back whatever ends the script
 (rocprofv3 --list-avail 2>/dev/null || rocprofv3 -L 2>/dev/null) | grep -i "lds" | head -60 > gpurun_out/ldsab/avail.txt
 cd /tmp && export TMPDIR=/tmp
 for v in A B; do
@@ -15,7 +16,7 @@ for v in A B; do
   for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INST_CYCLES_VMEM" \
               "SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_MEM_VIOLATIONS SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_ADDR_STALL"; do
     i=$((i+1))
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/ldsab_$v/pass$i -o p -- python3 "$ROOTDIR/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-two-stream-leg --no-parity > $ROOTDIR/gpurun_out/ldsab/${v}_pass$i.log 2>&1
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/ldsab_$v/pass$i -o p -- python3 "$ROOTDIR/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-one-stream-leg --streams 1 --no-parity > $ROOTDIR/gpurun_out/ldsab/${v}_pass$i.log 2>&1
     echo "$v pass $i rc=$?"
   done
   python3 - "$v" "$KERN" <<'PY' > $ROOTDIR/gpurun_out/ldsab/$v.txt

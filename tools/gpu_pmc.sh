@@ -14,7 +14,7 @@ for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
             "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
             "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/pass$i" -o p -- python3 "$ROOTDIR/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-two-stream-leg "$@" > "$OUT/pass$i.log" 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/pass$i" -o p -- python3 "$ROOTDIR/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-one-stream-leg --streams 1 "$@" > "$OUT/pass$i.log" 2>&1
   rc=$?
   echo "pass $i rc=$rc ($ctrs)"
   if [ $rc -ge 124 ]; then echo "timeout: stopping"; exit $rc; fi

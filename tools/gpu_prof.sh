@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 export PYTHONUNBUFFERED=1
 ROOTDIR=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOTDIR/$OUT" -o trace -- python3 "$ROOTDIR/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-two-stream-leg "$@" > "$ROOTDIR/$OUT/bench_under_rocprof.log" 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOTDIR/$OUT" -o trace -- python3 "$ROOTDIR/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-one-stream-leg --streams 1 "$@" > "$ROOTDIR/$OUT/bench_under_rocprof.log" 2>&1
 echo "rocprof rc=$?"
 cd "$ROOTDIR"
 find "$OUT" -name "*kernel_stats*.csv" | head -3
