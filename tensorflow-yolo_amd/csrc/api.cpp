@@ -746,10 +746,10 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
             sp.ksplit = pk.ks;
             std::string sym = dma_cfg_symbol_for(tile, f32net, sp);      // (the persistent form of the tap kernel where it takes the launch)
             if (pk.ks > 1) {        // the split-K instantiation of the tap kernel (its last template argument)
-                const size_t at = sym.rfind(", false>(");
-                if (at != std::string::npos) sym.replace(at, 9, ", true>(");
-                const size_t occ = sym.find("26, 4, 1, true>(");       // the in-launch pair on the 128 x 256 tile is built for one workgroup per CU
-                if (pk.pair && occ != std::string::npos) sym.replace(occ, 16, "26, 2, 1, true>(");
+                const size_t at = sym.rfind(", false, false>(");
+                if (at != std::string::npos) sym.replace(at, 16, ", true, false>(");
+                const size_t occ = sym.find("26, 4, 1, true, false>(");       // the in-launch pair on the 128 x 256 tile is built for one workgroup per CU
+                if (pk.pair && occ != std::string::npos) sym.replace(occ, 23, "26, 2, 1, true, false>(");
             }
             set_symbol(sym);
         } else {

@@ -226,6 +226,67 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, float4v (&acc
     }
 }
 
+// The common case of the fp16 nets as a LEAN epilogue (ConvParams.fast_epi, set by the launcher): fp16 output of the normal
+// index map, 16-byte aligned views below 2 GiB, Cout a multiple of 16, residual (if any) likewise.  The generic epilogue
+// above serves every view and output map through run-time branches: ~1 170 of the ~1 480 vector instructions a wave of the dominant
+// tap kernel issued (ISA count, profiles/r04_ablation.md) against 576 MFMAs -- selects on p.leaky, 64-bit address arithmetic per
+// fragment and access, a canonicalising v_max in front of every fmaxf, the pixel decode done twice.  Here: buffer addressing (one
+// 32-bit offset per fragment, invalid lanes carry an out-of-range offset instead of an exec mask), every residual chunk requested
+// before the first is used, leaky ReLU as mul + max (max(s x, x) with s = 0.1 or 1: no select; the conv kernels are compiled
+// with -fno-honor-nans, so no canonicalisation), + residual in float32 (a code path of its own, no select), ONE rounding, 16-byte stores.  Same values as the generic epilogue for every finite
+// input.  The accumulators start from the bias (conv_init_acc_bias).
+template <int TM, int TP, int PADQ, bool RES>
+__device__ __forceinline__ void conv_epilogue_fast_body(const ConvParams &p, float4v (&acc)[TM][TP], int cbase, int m_wave, int fr) {
+    typedef _Float16 T;
+    constexpr int CH = 4 * TM, EPC = 8, NQ = CH / EPC;
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u4;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(RES ? p.res : (const void *)p.out), 0,
+                                                                              RES ? p.res_bytes : 0u, 0x00020000);
+    const bool c_ok = cbase < p.Cout;
+    uint32_t ooff[TP];
+    uint4v rv[RES ? TP : 1][NQ];
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+        int n, rem, oy, ox;
+        const bool ok = conv_decode_pixel<PADQ>(p, m_wave + b * 16 + fr, n, rem, oy, ox) && c_ok;
+        const uint32_t o = (uint32_t)(((long long)n * p.out_img_stride + (long long)rem * p.out_ld + cbase) * 2);
+        ooff[b] = ok ? o : YOLO_INVALID_OFF;
+        if constexpr (RES) {
+            const uint32_t ro = (uint32_t)(((long long)n * p.res_img_stride + (long long)rem * p.res_ld + cbase) * 2);
+            const uint32_t roff = ok ? ro : YOLO_INVALID_OFF;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) rv[b][q] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, q * 16, 0));
+        }
+    }
+    const float slope = p.leaky ? 0.1f : 1.0f;
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            T t[EPC], r[EPC];
+            if constexpr (RES) __builtin_memcpy(r, &rv[b][q], 16);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int i = q * EPC + e;
+                float x = acc[i >> 2][b][i & 3];
+                x = fmaxf(slope * x, x);        // (-fno-honor-nans for the conv kernels, csrc/Makefile: no canonicalising v_max in front)
+                if constexpr (RES) x += (float)r[e];
+                t[e] = (T)x;
+            }
+            u4 u;
+            __builtin_memcpy(&u, t, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(u, rs_out, ooff[b], q * 16, 0);
+        }
+    }
+}
+
+template <int TM, int TP, int PADQ>
+__device__ __forceinline__ void conv_epilogue_fast(const ConvParams &p, float4v (&acc)[TM][TP], int cbase, int m_wave, int fr) {
+    if (p.has_res) conv_epilogue_fast_body<TM, TP, PADQ, true>(p, acc, cbase, m_wave, fr);
+    else conv_epilogue_fast_body<TM, TP, PADQ, false>(p, acc, cbase, m_wave, fr);
+}
+
 // conv + 2x2/2 max-pool (net/layers.py:70-81 behind net/layers.py:17-67; even H and W, so the pool's zero pad row / column is never
 // read) for the 2-D tiles of conv_tap.hip (PADQ 2): fragment b of a wave is tile row (first row of the wave) + b, TP is even and
 // tiles start on even rows, so the two rows of a pool window are fragments b, b + 1 of the SAME lane and its two columns are lanes

@@ -491,17 +491,17 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
 
 std::string dma_cfg_symbol_for(int cfg, bool f32, const ConvParams &p) {
     if (is_tap_cfg(cfg) && conv_tap_stream_ok(p, tap_variant(cfg))) return conv_tap_stream_symbol(tap_variant(cfg));
-    std::string sym = dma_cfg_symbol(cfg, f32);
+    std::string sym = dma_cfg_symbol(cfg, f32, is_tap_cfg(cfg) && !f32 && conv_fast_epilogue_ok(p));
     if (is_tap_cfg(cfg) && p.outmode == OUT_POOL2) {        // the fused-pool instantiation: template argument MODE 3 instead of 2
-        const size_t at = sym.rfind(", 2, false>(");
-        if (at != std::string::npos) sym.replace(at, 12, ", 3, false>(");
+        const size_t at = sym.rfind(", 2, false, false>(");
+        if (at != std::string::npos) sym.replace(at, 19, ", 3, false, false>(");
     }
     return sym;
 }
 
 // the name rocprofv3's kernel trace prints for the kernel a tile id runs (yolo_kernel_info.symbol)
-const char *dma_cfg_symbol(int cfg, bool f32) {
-    if (is_tap_cfg(cfg)) return conv_tap_symbol(tap_variant(cfg), f32);
+const char *dma_cfg_symbol(int cfg, bool f32, bool fast) {
+    if (is_tap_cfg(cfg)) return conv_tap_symbol(tap_variant(cfg), f32, fast);
     switch (cfg) {
 #define X(id, ...) case id: return "void yolo::conv_igemm_dma_kernel<" #__VA_ARGS__ ">(yolo::ConvParams)";
         YOLO_DMA_VARIANTS(X)

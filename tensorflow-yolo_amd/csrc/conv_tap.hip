@@ -66,7 +66,10 @@ constexpr int kTapStreamBiasFloats = 512;      // stream kernel: couts whose bia
 // SPLITK: the split-K instantiation (blockIdx.y = K split, raw float32 partial sums out; 128 x 128 tile only).  A template
 // parameter, not a run-time branch: with the branch in the code the register allocation of the big tiles changed (46-64
 // VGPRs spilled, scratch traffic doubling the kernel's HBM writes: profiles/r02_ablation.md).
-template <bool F32, int WM, int WN, int TM, int TP, int PRG, int OCC, int MODE, bool SPLITK>
+// FAST: the lean epilogue of conv_common.h (conv_epilogue_fast) instead of the generic one -- an instantiation of its own, not a
+// run-time branch: with both epilogues in one kernel the 128-register tiles spilled two patch-DMA offsets, reloaded inside the K
+// loop behind a vmcnt(0) that drains the DMA queue.  fp16, whole K, MODE 1 / 2.
+template <bool F32, int WM, int WN, int TM, int TP, int PRG, int OCC, int MODE, bool SPLITK, bool FAST = false>
 __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams p) {
     typedef typename std::conditional<F32, float, _Float16>::type T;
     constexpr bool TWO_D = MODE >= 2;       // MODE 3: the 2-D tiles of MODE 2 with the max-pool behind the conv taken in the epilogue
@@ -93,6 +96,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     if constexpr (F32 && (TP > 2 || OCC >= 6)) return;     // never launched (launch_conv_tap refuses): no registers for the second accumulator
     if constexpr (SPLITK && !(WM == 2 && WN == 4 && TM == 4 && (TP == 2 || (TP == 4 && !F32)) && MODE == 1)) return;    // split-K: the 128 x 128 tile; 128 x 256 (fp16) for the in-launch pair
     if constexpr (MODE == 3 && (TP % 2 != 0 || SPLITK)) return;      // split-K: the 128 x 128 tile only
+    static_assert(!FAST || (!F32 && !SPLITK && MODE != 3), "the lean epilogue: fp16, whole K, plain output");
     __shared__ __attribute__((aligned(16))) unsigned char smem[S * A_BYTES + 2 * P_BYTES];
     unsigned char *const smemP = smem + S * A_BYTES;
 
@@ -343,6 +347,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     } else {
         // (a template mode, not a run-time branch: with the branch in the code the 128 x (16 x 16) tile spilled 28 VGPRs)
         if constexpr (MODE == 3) conv_epilogue_pool2<T, TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
+        else if constexpr (FAST) conv_epilogue_fast<TM, TP, PADQ>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
         else conv_epilogue<T, TM, TP, PADQ, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
     }
 #ifdef YOLO_EXPERIMENT
@@ -653,10 +658,11 @@ bool conv_tap_fits(int variant, int W) {
     X(7, 2, 4, 4, 2, 12, 6, 2) \
     X(8, 1, 8, 2, 2, 27, 4, 2)
 
-const char *conv_tap_symbol(int variant, bool f32) {
+const char *conv_tap_symbol(int variant, bool f32, bool fast) {
     switch (variant) {
-#define X(id, ...) case id: return f32 ? "void yolo::conv3x3_tap_kernel<true, " #__VA_ARGS__ ", false>(yolo::ConvParams)" \
-                                       : "void yolo::conv3x3_tap_kernel<false, " #__VA_ARGS__ ", false>(yolo::ConvParams)";
+#define X(id, ...) case id: return f32 ? "void yolo::conv3x3_tap_kernel<true, " #__VA_ARGS__ ", false, false>(yolo::ConvParams)" \
+                                       : fast ? "void yolo::conv3x3_tap_kernel<false, " #__VA_ARGS__ ", false, true>(yolo::ConvParams)" \
+                                              : "void yolo::conv3x3_tap_kernel<false, " #__VA_ARGS__ ", false, false>(yolo::ConvParams)";
         YOLO_TAP_VARIANTS(X)
 #undef X
     default: return "";
@@ -701,7 +707,10 @@ static hipError_t launch_conv_tap_stream(const ConvParams &p0, int variant, hipS
     return hipGetLastError();
 }
 
-hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
+hipError_t launch_conv_tap(const ConvParams &p0, int variant, hipStream_t s) {
+    ConvParams p = p0;
+    static const bool no_fast_epi = getenv("YOLO_NO_FAST_EPI") != nullptr;        // A/B switch, read once (same results either way)
+    p.fast_epi = !no_fast_epi && conv_fast_epilogue_ok(p) ? 1 : 0;
     if (p.ksize != 3 || p.stride != 1 || p.pad != 1 || p.Ho != p.H || p.Wo != p.W || (p.cin_chunks & 3) || !conv_tap_fits(variant, p.W) ||
         (p.f32 && !conv_tap_f32_ok(variant)))
         return hipErrorInvalidValue;
@@ -733,6 +742,7 @@ hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s) {
     switch (variant) {
 #define X(id, ...) case id: \
         if (p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<true, __VA_ARGS__, false>), grid, dim3(512), 0, s, p); \
+        else if (p.fast_epi) hipLaunchKernelGGL((conv3x3_tap_kernel<false, __VA_ARGS__, false, true>), grid, dim3(512), 0, s, p); \
         else hipLaunchKernelGGL((conv3x3_tap_kernel<false, __VA_ARGS__, false>), grid, dim3(512), 0, s, p); \
         break;
         YOLO_TAP_VARIANTS(X)

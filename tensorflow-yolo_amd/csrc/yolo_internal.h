@@ -115,6 +115,7 @@ struct ConvParams {
     int *pair_cnt;
     uint32_t part_bytes;
     int stream;                // conv_tap.hip: run the persistent (stream) form where it applies
+    int fast_epi;              // conv_common.h: conv_epilogue_fast applies (set by the launchers: conv_fast_epilogue_ok)
     int dbg;                   // experiment flags (YOLO_CONV_DBG): 1 skip steady-state DMA, 2 skip MFMA phase
     int qW, qHW, Mq;           // conv_tap.hip: padded-linear pixel grid, row stride W+1, image stride (H+1)(W+1), total
     int t2_shift;              // conv_tap.hip MODE 2: log2 of the positions per 2-D tile (8: 16 x 16, 7: 8 x 16)
@@ -123,6 +124,11 @@ struct ConvParams {
     unsigned long long *trace; // conv_tap.hip: per-block phase timestamps (YOLO_CONV_TRACE experiment) or null
     FastDiv dHoWo, dWo, dqHW, dqW, dtiles_n, dtpt;   // set by the launchers (conv_set_divisors); dtpt: K stages per tap
 };
+// fp16 output through the normal index map, 16-byte aligned views below 2 GiB, whole 16-cout groups, no split-K: the lean epilogue
+inline bool conv_fast_epilogue_ok(const ConvParams &p) {
+    return !p.f32 && !p.out_f32 && p.outmode == OUT_NORMAL && p.vec_out && p.out_bytes && p.Cout % 16 == 0 && p.ksplit <= 1 &&
+           (!p.has_res || (p.vec_res && p.res_bytes));
+}
 inline void conv_set_divisors(ConvParams &p, int stages_per_tap) {
     p.dtpt = make_fastdiv((uint32_t)(stages_per_tap > 0 ? stages_per_tap : 1));
     p.dHoWo = make_fastdiv((uint32_t)p.HoWo);
@@ -264,8 +270,8 @@ bool conv_tap_f32_ok(int variant);            // float32 instantiation usable (t
 bool dma_cfg_f32_ok(int cfg);
 const char *dma_cfg_name(int cfg);
 // names exactly as rocprofv3's kernel trace prints them (yolo_kernel_info.symbol: joins bench.py's roofline to profiles/*.csv)
-const char *dma_cfg_symbol(int cfg, bool f32);
-const char *conv_tap_symbol(int variant, bool f32);
+const char *dma_cfg_symbol(int cfg, bool f32, bool fast = false);      // fast: the lean-epilogue instantiation of a tap tile
+const char *conv_tap_symbol(int variant, bool f32, bool fast = false);
 std::string dma_cfg_symbol_for(int cfg, bool f32, const ConvParams &p);      // the kernel that runs THIS launch (stream form included)
 const char *conv_tap_stream_symbol(int variant);
 std::string conv_symbol(int dtype, int cfg, bool perchunk);

@@ -438,7 +438,7 @@ def test_in_launch_pair_split_k(dtype, shape):
     syms = [ki.symbol.decode() for ki in infos]
     pair = [i for i, n in enumerate(names) if "+pairK" in n]
     assert len(pair) == 2, names
-    want_sym = "conv3x3_tap_kernel<false, 2, 4, 4, 4, 26, 2, 1, true>" if dtype == "fp16" else "conv3x3_tap_kernel<true, 2, 4, 4, 2, 28, 4, 1, true>"
+    want_sym = "conv3x3_tap_kernel<false, 2, 4, 4, 4, 26, 2, 1, true, false>" if dtype == "fp16" else "conv3x3_tap_kernel<true, 2, 4, 4, 2, 28, 4, 1, true, false>"
     assert all(want_sym in syms[i] for i in pair), syms
     a = eng.forward(x).cpu().numpy()
     b = eng.forward(x).cpu().numpy()
