@@ -399,6 +399,32 @@ size_t splitk_slab_bytes(const yolo_net *net) {
     return need ? kPairCounterBytes + (need + 4095) / 4096 * 4096 : 0;
 }
 
+// Back-to-back 1x1: does the launch of conv `ki` at this batch also compute the 1x1 conv `ki + 1` (plan.cpp marked the pair)?
+// Yes when the tile the batch picks holds all 128 couts of 256 positions per workgroup and has the fused instantiation: the 2-D
+// 128 x 256 tap tile (12) or the 128 x 256 K32 LDS-DMA tile (6), whole K, lean epilogue.  On success `p` (the 3x3's launch
+// parameters) carries the 1x1's weights, bias and output view.
+bool conv_fuse2(const yolo_net *net, size_t ki, const Ptrs *P, int batch, ConvParams &p, size_t slab_bytes) {
+    const Kernel &k = net->kernels[ki];
+    if (!k.fuse2_next || ki + 1 >= net->kernels.size() || !net->kernels[ki + 1].fuse2_prev) return false;
+    const ConvPick pk = pick_conv(net, k, p, k.tile, slab_bytes);
+    if ((pk.tile != 12 && pk.tile != 6) || pk.ks > 1 || pk.pair || !conv_fast_epilogue_ok(p)) return false;
+    if ((pk.tile == 12) != (p.has_res != 0)) return false;      // the two instantiations built: tap tile + residual, LDS-DMA tile without
+    const Kernel &b = net->kernels[ki + 1];
+    const long long ob = (long long)batch * b.out.img_stride * net->esize;
+    if (ob <= 0 || ob > 0x7ffffff0LL) return false;
+    p.fuse2 = 1;
+    p.w2 = net->dev_weights + b.w_off;
+    p.w2_bytes = (uint32_t)b.w_bytes;
+    p.wrow2_bytes = (uint32_t)b.ktiles * 128;
+    p.b2 = reinterpret_cast<const float *>(net->dev_weights + b.b_off);
+    p.out2 = P ? P->view_ptr(b.out) : nullptr;
+    p.out2_bytes = (uint32_t)ob;
+    p.out2_ld = b.out.ld;
+    p.out2_img_stride = b.out.img_stride;
+    p.leaky2 = b.leaky;
+    return true;
+}
+
 hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParams &p0, int tile_req, hipStream_t s, int arena = 0) {
     const size_t slab = net->splitk_bytes / (size_t)net->arenas / 256 * 256;      // concurrent parts (streams) must not share a slab
     const size_t data_bytes = slab > kPairCounterBytes ? slab - kPairCounterBytes : 0;
@@ -434,6 +460,7 @@ int run_forward_pass(yolo_net *net, const float *in_dev, int batch, float *out_d
     const int dtype = net->opt.dtype;
     const int epc = net->epc;
     long long obj_rows_written = 0;          // rows of the compact objectness array the head convs of this pass fill
+    bool fused2_done = false;                // the previous conv launch has computed this 1x1 conv too (back-to-back fusion)
     for (size_t ki = 0; ki < net->kernels.size(); ++ki) {
         const Kernel &k = net->kernels[ki];
         hipError_t e = hipSuccess;
@@ -476,10 +503,15 @@ int run_forward_pass(yolo_net *net, const float *in_dev, int batch, float *out_d
                 break;
             }
             if (k.stem == 3) break;     // computed by the stem kernel
+            if (k.fuse2_prev && fused2_done) { fused2_done = false; break; }       // computed by the conv in front of it
             ConvParams p;
             int rc = make_conv_params(net, k, P, batch, p);
             if (rc) return rc;
             if (k.head && p.obj_out) obj_rows_written += (long long)p.Ho * p.Wo * p.obj_na;
+            {
+                const size_t slab = net->splitk_bytes / (size_t)net->arenas / 256 * 256;
+                fused2_done = conv_fuse2(net, ki, &P, batch, p, slab > kPairCounterBytes ? slab - kPairCounterBytes : 0);
+            }
             e = launch_conv_any(net, k, p, k.tile, s, P.arena);
             break;
         }
@@ -735,9 +767,27 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         }
         // which kernel runs at max_batch (bench.py runs at max_batch): the same decision the launch path takes
         ConvParams sp;
-        conv_shape_params(net, k, (net->opt.max_batch + net->arenas - 1) / net->arenas, sp);
+        const int per_arena = (net->opt.max_batch + net->arenas - 1) / net->arenas;
+        conv_shape_params(net, k, per_arena, sp);
         const size_t slab_i = net->splitk_bytes / (size_t)net->arenas / 256 * 256;
-        const ConvPick pk = pick_conv(net, k, sp, k.tile, slab_i > kPairCounterBytes ? slab_i - kPairCounterBytes : 0);
+        const size_t slab_d = slab_i > kPairCounterBytes ? slab_i - kPairCounterBytes : 0;
+        if (k.fuse2_prev && kernel > 0) {       // computed by the conv in front of it at this batch?
+            ConvParams pp;
+            conv_shape_params(net, net->kernels[kernel - 1], per_arena, pp);
+            if (conv_fuse2(net, (size_t)kernel - 1, nullptr, per_arena, pp, slab_d)) {
+                out->flops = 0; out->bytes = 0; out->weight_bytes = 0;
+                snprintf(out->name, sizeof out->name, "conv_igemm<fused into the conv in front>");
+                return YOLO_OK;
+            }
+        }
+        const bool fused2 = conv_fuse2(net, (size_t)kernel, nullptr, per_arena, sp, slab_d);
+        if (fused2) {       // this launch also computes the 1x1 behind it: its work and its output belong here
+            const Kernel &b2 = net->kernels[kernel + 1];
+            out->flops += 2.0 * li.H * li.W * b2.cout * b2.cin;
+            out->bytes += elems(b2.out) * esz(b2.out);
+            out->weight_bytes += (double)b2.cout * b2.cin * net->esize + 4.0 * b2.cout;
+        }
+        const ConvPick pk = pick_conv(net, k, sp, k.tile, slab_d);
         const int tile = pk.tile;
         const bool f32net = net->opt.dtype == YOLO_DTYPE_F32;
         if (tile > 0) {
@@ -746,10 +796,10 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
             sp.ksplit = pk.ks;
             std::string sym = dma_cfg_symbol_for(tile, f32net, sp);      // (the persistent form of the tap kernel where it takes the launch)
             if (pk.ks > 1) {        // the split-K instantiation of the tap kernel (its last template argument)
-                const size_t at = sym.rfind(", false, false>(");
-                if (at != std::string::npos) sym.replace(at, 16, ", true, false>(");
-                const size_t occ = sym.find("26, 4, 1, true, false>(");       // the in-launch pair on the 128 x 256 tile is built for one workgroup per CU
-                if (pk.pair && occ != std::string::npos) sym.replace(occ, 23, "26, 2, 1, true, false>(");
+                const size_t at = sym.rfind(", false, false, false>(");
+                if (at != std::string::npos) sym.replace(at, 23, ", true, false, false>(");
+                const size_t occ = sym.find("26, 4, 1, true, false, false>(");       // the in-launch pair on the 128 x 256 tile is built for one workgroup per CU
+                if (pk.pair && occ != std::string::npos) sym.replace(occ, 30, "26, 2, 1, true, false, false>(");
             }
             set_symbol(sym);
         } else {
@@ -760,6 +810,10 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         if (k.outmode == OUT_POOL2) {
             const size_t n = strlen(out->name);
             snprintf(out->name + n, sizeof out->name - n, "+pool");
+        }
+        if (fused2) {
+            const size_t n = strlen(out->name);
+            snprintf(out->name + n, sizeof out->name - n, "+1x1");
         }
         if (pk.pair) {              // K in two halves inside the launch
             const size_t n = strlen(out->name);

@@ -287,6 +287,165 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvParams &p, float4v 
     else conv_epilogue_fast_body<TM, TP, PADQ, false>(p, acc, cbase, m_wave, fr);
 }
 
+// BACK-TO-BACK 1x1 (ConvParams.fuse2): the 1x1 conv that reads this conv's output (Darknet-53: the first layer of the next
+// residual block, net/v3.py:16-19) computed by the SAME workgroup, when its tile holds ALL 128 output channels of its 256 positions
+// (8 waves as 2 x 4, TM = TP = 4) and the 1x1 has 64 filters: t[64][256] = W2[64][128] . y[128][256].  The 1x1 launches at 152 x 152
+// are HBM-bound re-reads of what the conv in front of them has just written (189 MB read + 95 MB written in 65 us each at batch 32);
+// here y goes to HBM as before (the shortcut two layers on and the next 3x3 need it) and, in fp16 exactly as stored, into LDS -- the
+// K loop's rings are dead -- as a [256 positions][128 channels] image, chunk c of row r at c ^ (r & 15): conflict-free for the
+// ds_write_b128 of the epilogue (8 consecutive rows per write group) and for the ds_read_b128 of the second pass (16 rows of one
+// chunk column per lane group).  Second pass: wave w owns positions 32 w .. 32 w + 31 and all 64 filters; A operand = W2 from an LDS
+// image behind the first (LDS-DMA, once per workgroup), row of tile a for lane row m = filter 16 (m >> 2) + 4 a + (m & 3), so
+// that a lane ends up with 16 CONTIGUOUS filters of its position (32-byte stores); bias as the accumulators' initial value;
+// leaky; one rounding.  Same arithmetic as the stand-alone launch up to the
+// K order of the 128-deep sum (fp32 accumulation either way).
+constexpr int kFuse2ImageBytes = 256 * 256;        // [256 positions][128 channels] fp16
+constexpr int kFuse2LdsBytes = kFuse2ImageBytes + 64 * 256;       // + W2 [64 filters][128 channels]: 80 KiB, two workgroups per CU
+
+typedef __attribute__((address_space(3))) void conv_lds_void;
+__device__ __forceinline__ void conv_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char *lds_dst, uint32_t voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (conv_lds_void *)lds_dst, 16, voff, 0, 0, 0);
+#else
+    (void)rsrc; (void)lds_dst; (void)voff;
+#endif
+}
+
+template <int PADQ, bool RES>
+__device__ __forceinline__ void conv_epilogue_fused_1x1_body(const ConvParams &p, float4v (&acc)[4][4], int q0, int wm, int wn, int wave, int lane,
+                                                             unsigned char *smem) {
+    typedef _Float16 T;
+    constexpr int TP = 4, CH = 16, EPC = 8, NQ = 2;
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u4;
+    const int fr = lane & 15, fq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(RES ? p.res : (const void *)p.out), 0,
+                                                                              RES ? p.res_bytes : 0u, 0x00020000);
+    const int cbase = wm * 64 + fq * CH;            // (n0 = 0: the tile holds every cout)
+    const int m_wave = q0 + wn * (TP * 16);
+    // ---- first pass epilogue: y -> HBM and -> LDS ----------------------------------------------------------------------------------
+    __syncthreads();                                // every wave has left the K loop: the rings are free
+    // W2 (64 filters x 128 channels = 16 KiB) comes into LDS ONCE per workgroup, behind the image, by LDS-DMA -- two wave
+    // instructions per wave, in flight under the whole first-pass epilogue.  (Read per wave straight from L2 into registers -- 16 KiB
+    // x 8 waves per workgroup -- it cost 44 us per launch, as much as the 1x1 launch it replaces: profiles/r04_ablation.md.)
+    // Row r = filter r, 16 chunks of 16 bytes; chunk c of row r at c ^ (4 (r >> 4) + (r & 3)): the 16 rows of an A fragment
+    // (filters 16 g + 4 a + j for lane row 4 g + j) land on 16 different chunk columns.
+    {
+        const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w2), 0, p.w2_bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = 2 * wave + j;             // 1 KiB piece: rows 4 i .. 4 i + 3
+            const int row = 4 * i + (lane >> 4);
+            const int logical = (lane & 15) ^ (((row >> 4) << 2) | (row & 3));
+            conv_dma16(rs_w2, smem + kFuse2ImageBytes + i * 1024, (uint32_t)row * p.wrow2_bytes + (uint32_t)(logical << 4));
+        }
+    }
+    uint32_t ooff[TP];
+    uint4v rv[RES ? TP : 1][NQ];
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+        int n, rem, oy, ox;
+        const bool ok = conv_decode_pixel<PADQ>(p, m_wave + b * 16 + fr, n, rem, oy, ox);
+        const uint32_t o = (uint32_t)(((long long)n * p.out_img_stride + (long long)rem * p.out_ld + cbase) * 2);
+        ooff[b] = ok ? o : YOLO_INVALID_OFF;
+        if constexpr (RES) {
+            const uint32_t ro = (uint32_t)(((long long)n * p.res_img_stride + (long long)rem * p.res_ld + cbase) * 2);
+            const uint32_t roff = ok ? ro : YOLO_INVALID_OFF;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) rv[b][q] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, q * 16, 0));
+        }
+    }
+    // (y goes to LDS only here; its global stores come LAST, re-read from the image: `vmcnt` retires in order, and the W2 loads of the
+    // second pass queued behind eight HBM stores per lane cost every workgroup ~7 us -- the first build of this fusion was no
+    // faster than the two launches)
+    const float slope = p.leaky ? 0.1f : 1.0f;
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+        const int r = wn * 64 + b * 16 + fr;        // row of the LDS image (r & 15 == fr)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            T t[EPC], rr[EPC];
+            if constexpr (RES) __builtin_memcpy(rr, &rv[b][q], 16);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int i = q * EPC + e;
+                float x = acc[i >> 2][b][i & 3];
+                x = fmaxf(slope * x, x);
+                if constexpr (RES) x += (float)rr[e];
+                t[e] = (T)x;
+            }
+            u4 u;
+            __builtin_memcpy(&u, t, 16);
+            const int c = wm * 8 + fq * 2 + q;      // 16-byte chunk of the row: channels 8 c .. 8 c + 7
+            *reinterpret_cast<u4 *>(smem + r * 256 + ((c ^ fr) << 4)) = u;
+        }
+    }
+    // ---- second pass ------------------------------------------------------------------------------------------------------------------
+    float4v acc2[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float4v bv = *reinterpret_cast<const float4v *>(p.b2 + fq * 16 + 4 * a);
+        acc2[a][0] = bv; acc2[a][1] = bv;
+    }
+    __syncthreads();                                // the image is complete
+    const unsigned char *Y = smem + (wave * 32 + fr) * 256;
+    const unsigned char *W2 = smem + kFuse2ImageBytes + ((fr >> 2) * 16 + (fr & 3)) * 256;      // + 4 a rows: filter 16 (fr >> 2) + 4 a + (fr & 3)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int col = ((4 * ks + fq) ^ fr) << 4;  // (both images swizzle a fragment row by its lane row fr)
+        uint4v yb[2], wa[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) wa[a] = *reinterpret_cast<const uint4v *>(W2 + a * 4 * 256 + col);
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt) yb[bt] = *reinterpret_cast<const uint4v *>(Y + bt * 16 * 256 + col);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int bt = 0; bt < 2; ++bt) acc2[a][bt] = mma_chunk<T>(wa[a], yb[bt], acc2[a][bt]);
+    }
+    const __amdgpu_buffer_rsrc_t rs_out2 = __builtin_amdgcn_make_buffer_rsrc(p.out2, 0, p.out2_bytes, 0x00020000);
+    const float slope2 = p.leaky2 ? 0.1f : 1.0f;
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt) {
+        int n, rem, oy, ox;
+        const bool ok = conv_decode_pixel<PADQ>(p, q0 + wave * 32 + bt * 16 + fr, n, rem, oy, ox);
+        const uint32_t o = ok ? (uint32_t)(((long long)n * p.out2_img_stride + (long long)rem * p.out2_ld + fq * 16) * 2) : YOLO_INVALID_OFF;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            T t[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int i = q * EPC + e;          // filter 16 fq + i = tile (i >> 2), row 4 fq + (i & 3)
+                const float x = acc2[i >> 2][bt][i & 3];
+                t[e] = (T)fmaxf(slope2 * x, x);
+            }
+            u4 u;
+            __builtin_memcpy(&u, t, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(u, rs_out2, o, q * 16, 0);
+        }
+    }
+    // y -> HBM: every lane re-reads the chunks it wrote itself (no barrier needed)
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+        const int r = wn * 64 + b * 16 + fr;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int c = wm * 8 + fq * 2 + q;
+            const u4 u = *reinterpret_cast<const u4 *>(smem + r * 256 + ((c ^ fr) << 4));
+            __builtin_amdgcn_raw_buffer_store_b128(u, rs_out, ooff[b], q * 16, 0);
+        }
+    }
+}
+
+// RES is a compile-time property of the instantiation, not a run-time branch: with both bodies in one kernel the register
+// allocator spilled 40 registers of the second pass (each body alone: none).  Darknet-53 has exactly the two cases built:
+// the residual block's 3x3 (tap kernel, RES) and the stride-2 conv into the stage (LDS-DMA kernel, no residual).
+template <int PADQ, bool RES>
+__device__ __forceinline__ void conv_epilogue_fused_1x1(const ConvParams &p, float4v (&acc)[4][4], int q0, int wm, int wn, int wave, int lane,
+                                                        unsigned char *smem) {
+    conv_epilogue_fused_1x1_body<PADQ, RES>(p, acc, q0, wm, wn, wave, lane, smem);
+}
+
 // conv + 2x2/2 max-pool (net/layers.py:70-81 behind net/layers.py:17-67; even H and W, so the pool's zero pad row / column is never
 // read) for the 2-D tiles of conv_tap.hip (PADQ 2): fragment b of a wave is tile row (first row of the wave) + b, TP is even and
 // tiles start on even rows, so the two rows of a pool window are fragments b, b + 1 of the SAME lane and its two columns are lanes

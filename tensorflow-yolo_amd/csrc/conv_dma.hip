@@ -52,7 +52,9 @@ __device__ __forceinline__ int lds_swz(int r) {
 // OCC = waves per SIMD the register budget must allow (2: one workgroup per CU, 4: two per CU, so that
 // one workgroup's epilogue -- ~190 MB of residual reads + output writes per 76x76 layer -- overlaps the
 // other's MFMA loop; with one lock-stepped workgroup per CU that traffic was 44 % of the layer time).
-template <int WM, int WN, int TM, int TP, int S, int BKC, int OCC>
+// FUSE2: the 1x1 conv behind this one computed by the same workgroups (conv_common.h: conv_epilogue_fused_1x1); the 128 x 256 K32
+// tile only (all 128 couts of 256 pixels in one workgroup).
+template <int WM, int WN, int TM, int TP, int S, int BKC, int OCC, bool FUSE2 = false>
 __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvParams p) {
     typedef _Float16 T;
     static_assert(WM * WN == 8, "eight waves per workgroup");
@@ -71,7 +73,8 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
     constexpr int CH = 4 * TM;
     constexpr int TILE_BYTES = (NA + NB) * ROWB;
     static_assert(JB >= 1 && (A_ALL || JA_TOT < 8), "unsupported tile for the DMA mapping");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[S * TILE_BYTES];
+    constexpr int LDS_BYTES = FUSE2 && kFuse2LdsBytes > S * TILE_BYTES ? kFuse2LdsBytes : S * TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
     const int tid = threadIdx.x;
 #ifdef YOLO_EXPERIMENT      // block trace (tools/trace_blocks.py); not in the product build
@@ -215,6 +218,10 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
     if (p.dbg & 4) return;             // experiment: no epilogue
     const unsigned long long t_loop = p.trace ? wall_clock64() : 0ull;
 #endif
+    if constexpr (FUSE2) {
+        static_assert(!FUSE2 || (WM == 2 && WN == 4 && TM == 4 && TP == 4 && 2 * LDS_BYTES <= 163840), "back-to-back 1x1: 128 x 256 tile, two per CU");
+        conv_epilogue_fused_1x1<0, false>(p, acc, m0, wm, wn, wave, lane, smem);      // (the stride-2 conv into a stage: no residual)
+    } else
     if (p.out_f32 && !p.vec_out && p.outmode == OUT_NORMAL && !p.has_res) {      // head conv: coalesced float32 rows via LDS
         static_assert(8 * 16 * kStagePitch(TM) * 4 <= S * TILE_BYTES, "staging slabs must fit in the ring");
         __syncthreads();            // every wave is done reading the ring
@@ -405,6 +412,11 @@ const char *dma_cfg_name(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg
 
 static hipError_t launch_dma_tile(const ConvParams &p, int cfg, hipStream_t s) {
     const dim3 grid((unsigned)p.n_blocks), block(512);
+    if (p.fuse2) {          // back-to-back 1x1: the 128 x 256 K32 tile
+        if (cfg != 6 || !conv_fast_epilogue_ok(p) || p.has_res || p.n_tiles_n != 1 || p.Cout != 128 || !p.w2 || !p.b2 || !p.out2 || !p.out2_bytes) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<2, 4, 4, 4, 3, 4, 4, true>), grid, block, 0, s, p);
+        return hipGetLastError();
+    }
     switch (cfg) {
 #define X(id, ...) case id: hipLaunchKernelGGL((conv_igemm_dma_kernel<__VA_ARGS__>), grid, block, 0, s, p); break;
         YOLO_DMA_VARIANTS(X)
@@ -490,11 +502,13 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
 }
 
 std::string dma_cfg_symbol_for(int cfg, bool f32, const ConvParams &p) {
+    if (p.fuse2) return cfg == 6 ? "void yolo::conv_igemm_dma_kernel<2, 4, 4, 4, 3, 4, 4, true>(yolo::ConvParams)"
+                                 : "void yolo::conv3x3_tap_kernel<false, 2, 4, 4, 4, 27, 4, 2, false, true, true>(yolo::ConvParams)";
     if (is_tap_cfg(cfg) && conv_tap_stream_ok(p, tap_variant(cfg))) return conv_tap_stream_symbol(tap_variant(cfg));
     std::string sym = dma_cfg_symbol(cfg, f32, is_tap_cfg(cfg) && !f32 && conv_fast_epilogue_ok(p));
     if (is_tap_cfg(cfg) && p.outmode == OUT_POOL2) {        // the fused-pool instantiation: template argument MODE 3 instead of 2
-        const size_t at = sym.rfind(", 2, false, false>(");
-        if (at != std::string::npos) sym.replace(at, 19, ", 3, false, false>(");
+        const size_t at = sym.rfind(", 2, false, false, false>(");
+        if (at != std::string::npos) sym.replace(at, 26, ", 3, false, false, false>(");
     }
     return sym;
 }
@@ -503,7 +517,7 @@ std::string dma_cfg_symbol_for(int cfg, bool f32, const ConvParams &p) {
 const char *dma_cfg_symbol(int cfg, bool f32, bool fast) {
     if (is_tap_cfg(cfg)) return conv_tap_symbol(tap_variant(cfg), f32, fast);
     switch (cfg) {
-#define X(id, ...) case id: return "void yolo::conv_igemm_dma_kernel<" #__VA_ARGS__ ">(yolo::ConvParams)";
+#define X(id, ...) case id: return "void yolo::conv_igemm_dma_kernel<" #__VA_ARGS__ ", false>(yolo::ConvParams)";
         YOLO_DMA_VARIANTS(X)
 #undef X
     default: return "";

@@ -69,7 +69,9 @@ constexpr int kTapStreamBiasFloats = 512;      // stream kernel: couts whose bia
 // FAST: the lean epilogue of conv_common.h (conv_epilogue_fast) instead of the generic one -- an instantiation of its own, not a
 // run-time branch: with both epilogues in one kernel the 128-register tiles spilled two patch-DMA offsets, reloaded inside the K
 // loop behind a vmcnt(0) that drains the DMA queue.  fp16, whole K, MODE 1 / 2.
-template <bool F32, int WM, int WN, int TM, int TP, int PRG, int OCC, int MODE, bool SPLITK, bool FAST = false>
+// FUSE2: FAST + the 1x1 conv behind this one computed by the same workgroups (conv_common.h: conv_epilogue_fused_1x1); the
+// 128 x 256 2-D tile only (all 128 couts of 256 positions in one workgroup).
+template <bool F32, int WM, int WN, int TM, int TP, int PRG, int OCC, int MODE, bool SPLITK, bool FAST = false, bool FUSE2 = false>
 __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams p) {
     typedef typename std::conditional<F32, float, _Float16>::type T;
     constexpr bool TWO_D = MODE >= 2;       // MODE 3: the 2-D tiles of MODE 2 with the max-pool behind the conv taken in the epilogue
@@ -97,7 +99,9 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     if constexpr (SPLITK && !(WM == 2 && WN == 4 && TM == 4 && (TP == 2 || (TP == 4 && !F32)) && MODE == 1)) return;    // split-K: the 128 x 128 tile; 128 x 256 (fp16) for the in-launch pair
     if constexpr (MODE == 3 && (TP % 2 != 0 || SPLITK)) return;      // split-K: the 128 x 128 tile only
     static_assert(!FAST || (!F32 && !SPLITK && MODE != 3), "the lean epilogue: fp16, whole K, plain output");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[S * A_BYTES + 2 * P_BYTES];
+    static_assert(!FUSE2 || (FAST && WM == 2 && WN == 4 && TM == 4 && TP == 4), "back-to-back 1x1: the 128 x 256 tiles");
+    constexpr int LDS_BYTES = FUSE2 && kFuse2LdsBytes > S * A_BYTES + 2 * P_BYTES ? kFuse2LdsBytes : S * A_BYTES + 2 * P_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     unsigned char *const smemP = smem + S * A_BYTES;
 
     const int tid = threadIdx.x;
@@ -347,6 +351,10 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     } else {
         // (a template mode, not a run-time branch: with the branch in the code the 128 x (16 x 16) tile spilled 28 VGPRs)
         if constexpr (MODE == 3) conv_epilogue_pool2<T, TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
+        else if constexpr (FUSE2) {
+            static_assert(!FUSE2 || 2 * LDS_BYTES <= 163840, "two workgroups per CU");
+            conv_epilogue_fused_1x1<PADQ, true>(p, acc, q0, wm, wn, wave, lane, smem);       // (the residual block's 3x3: with residual)
+        }
         else if constexpr (FAST) conv_epilogue_fast<TM, TP, PADQ>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
         else conv_epilogue<T, TM, TP, PADQ, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
     }
@@ -660,9 +668,9 @@ bool conv_tap_fits(int variant, int W) {
 
 const char *conv_tap_symbol(int variant, bool f32, bool fast) {
     switch (variant) {
-#define X(id, ...) case id: return f32 ? "void yolo::conv3x3_tap_kernel<true, " #__VA_ARGS__ ", false, false>(yolo::ConvParams)" \
-                                       : fast ? "void yolo::conv3x3_tap_kernel<false, " #__VA_ARGS__ ", false, true>(yolo::ConvParams)" \
-                                              : "void yolo::conv3x3_tap_kernel<false, " #__VA_ARGS__ ", false, false>(yolo::ConvParams)";
+#define X(id, ...) case id: return f32 ? "void yolo::conv3x3_tap_kernel<true, " #__VA_ARGS__ ", false, false, false>(yolo::ConvParams)" \
+                                       : fast ? "void yolo::conv3x3_tap_kernel<false, " #__VA_ARGS__ ", false, true, false>(yolo::ConvParams)" \
+                                              : "void yolo::conv3x3_tap_kernel<false, " #__VA_ARGS__ ", false, false, false>(yolo::ConvParams)";
         YOLO_TAP_VARIANTS(X)
 #undef X
     default: return "";
@@ -737,6 +745,11 @@ hipError_t launch_conv_tap(const ConvParams &p0, int variant, hipStream_t s) {
         else if (variant == 8 && !p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<false, 1, 8, 2, 2, 27, 4, 3, false>), grid, dim3(512), 0, s, p);
         else if (variant == 8) hipLaunchKernelGGL((conv3x3_tap_kernel<true, 1, 8, 2, 2, 27, 4, 3, false>), grid, dim3(512), 0, s, p);
         else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
+    if (p.fuse2) {          // back-to-back 1x1: the 2-D 128 x 256 tile with the lean epilogue
+        if (variant != 4 || !p.fast_epi || !p.has_res || p.n_tiles_n != 1 || p.Cout != 128 || !p.w2 || !p.b2 || !p.out2 || !p.out2_bytes) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((conv3x3_tap_kernel<false, 2, 4, 4, 4, 27, 4, 2, false, true, true>), grid, dim3(512), 0, s, p);
         return hipGetLastError();
     }
     switch (variant) {

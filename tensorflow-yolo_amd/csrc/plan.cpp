@@ -406,6 +406,23 @@ struct Planner {
                     k.stem = 3;
                     k.note += " computed inside the stem kernel (no launch)";
                 }
+                // Back-to-back 1x1 (conv_common.h: conv_epilogue_fused_1x1): a 1x1 128 -> 64 conv whose input is exactly what the 3x3
+                // conv in front of it writes, where that conv's workgroups hold all 128 couts of their positions (Darknet-53 at
+                // 152 x 152: the stride-2 conv into the stage and the first residual block's 3x3, each followed by the next block's
+                // 1x1).  Structural conditions here; whether a launch takes the fused instantiation depends on the tile its batch
+                // picks (api.cpp: conv_fuse2), else the 1x1 runs as a launch of its own.
+                if (!net->kernels.empty() && net->opt.dtype == YOLO_DTYPE_F16 && !net->opt.keep_all && !getenv("YOLO_NO_FUSE2") &&
+                    d.ksize == 1 && d.stride == 1 && d.filters == 64 && cin == 128 && f.kind == 0 && !has_head[i] && !k.out.f32 &&
+                    k.out.ld % epc == 0 && (k.out.base + k.out.coff) % epc == 0 && k.out.img_stride % epc == 0) {
+                    Kernel &c = net->kernels.back();
+                    if (c.kind == K_CONV && c.layer == s && c.stem == 0 && c.cout == 128 && c.ksize == 3 && c.cpt % 4 == 0 &&
+                        c.outmode == OUT_NORMAL && !c.head && !c.out.f32 && c.out.buf == k.in.buf && c.out.ld == k.in.ld &&
+                        c.out.coff == k.in.coff && c.out.base == k.in.base && c.out.img_stride == k.in.img_stride) {
+                        c.fuse2_next = 1;
+                        k.fuse2_prev = 1;
+                        k.note += " (computed by the conv in front of it where that launch holds all 128 channels per workgroup)";
+                    }
+                }
                 net->kernels.push_back(k);
                 L[key].view = k.out; L[key].materialised = true;
                 if (key != i) { L[i].materialised = false; }
@@ -569,6 +586,9 @@ struct Planner {
                 B[v->buf].first = std::min(B[v->buf].first, k);
                 B[v->buf].last = std::max(B[v->buf].last, k);
             }
+            // back-to-back 1x1: its output is written by the launch of the conv IN FRONT of it -- alive one kernel earlier, or it
+            // could be given the bytes of a tensor that launch still reads (its own input dies there)
+            if (K[k].fuse2_prev && k > 0 && K[k].out.buf >= 0) B[K[k].out.buf].first = std::min(B[K[k].out.buf].first, k - 1);
         }
         const size_t align = 4096;
         // Multi-stream forward (yolo_net_options.streams / YOLO_STREAMS): the batch runs as independent parts, each in its

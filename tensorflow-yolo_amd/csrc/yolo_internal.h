@@ -116,6 +116,14 @@ struct ConvParams {
     uint32_t part_bytes;
     int stream;                // conv_tap.hip: run the persistent (stream) form where it applies
     int fast_epi;              // conv_common.h: conv_epilogue_fast applies (set by the launchers: conv_fast_epilogue_ok)
+    // back-to-back 1x1 (conv_common.h: conv_epilogue_fused_1x1): the 1x1 conv behind this one, computed by the same workgroups
+    int fuse2;                 // 1: w2 .. are set and the launch runs the fused instantiation
+    const void *w2;            // packed weights of the 1x1 ([128 rows][wrow2_bytes], natural filter order), 64 filters x 128 channels
+    const float *b2;           // its folded bias
+    void *out2;                // its output view (fp16, 16-byte aligned strides)
+    uint32_t w2_bytes, wrow2_bytes, out2_bytes;
+    int out2_ld, leaky2;
+    long long out2_img_stride;
     int dbg;                   // experiment flags (YOLO_CONV_DBG): 1 skip steady-state DMA, 2 skip MFMA phase
     int qW, qHW, Mq;           // conv_tap.hip: padded-linear pixel grid, row stride W+1, image stride (H+1)(W+1), total
     int t2_shift;              // conv_tap.hip MODE 2: log2 of the positions per 2-D tile (8: 16 x 16, 7: 8 x 16)
@@ -309,6 +317,9 @@ struct Kernel {
     int pool_fused = 0;        // K_FIRST: the max-pool layer behind it is taken in the same kernel
     int stem = 0;              // 1: first-layer kernel fused away into the next conv; 2: this conv runs as stem.hip with it;
                                // 3: this 1x1 conv is computed by the stem kernel in front of it (no launch)
+    int fuse2_next = 0;        // the NEXT kernel is a 1x1 128 -> 64 conv on this conv's output that the fused instantiation of this launch
+                               // can compute (conv_common.h: conv_epilogue_fused_1x1); whether it does is decided per launch (api.cpp: conv_fuse2)
+    int fuse2_prev = 0;        // ... and the mark on that 1x1: skipped when the conv in front of it has computed it
     size_t w_off = 0, b_off = 0, w_bytes = 0;   // inside the device weight blob
     size_t w_src = 0;                           // first float of this conv in the Darknet stream
     int batch_norm = 0;

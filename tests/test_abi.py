@@ -189,19 +189,20 @@ def test_dominant_kernel_register_allocation_is_guarded():
         elif cur and ":" in t:
             k, v = t.split(":", 1)
             rows[cur][k.strip()] = v.strip()
-    want = {   # mangled template arguments: F32, WM, WN, TM, TP, PRG, OCC, MODE, SPLITK, FAST -> (max spilled VGPRs, waves / SIMD)
+    want = {   # mangled template arguments: F32, WM, WN, TM, TP, PRG, OCC, MODE, SPLITK, FAST, FUSE2 -> (max spilled VGPRs, waves / SIMD)
         # FAST (Lb1 at the end) = the lean-epilogue instantiations the YOLOv3 step runs; Lb0 = the generic epilogue (any view / output map)
-        "ILb0ELi2ELi4ELi4ELi4ELi26ELi4ELi1ELb0ELb1EE": (0, 4),      # 128 x 256, two workgroups per CU: the roofline kernel
-        "ILb0ELi2ELi4ELi4ELi4ELi26ELi4ELi1ELb0ELb0EE": (0, 4),
-        "ILb0ELi2ELi4ELi4ELi4ELi27ELi4ELi2ELb0ELb1EE": (0, 4),      # 128 x (16 x 16) 2-D tile (152 x 152 layers)
-        "ILb0ELi2ELi4ELi4ELi4ELi27ELi4ELi2ELb0ELb0EE": (0, 4),
-        "ILb0ELi2ELi4ELi8ELi4ELi26ELi2ELi1ELb0ELb1EE": (0, 2),      # 256 x 256
-        "ILb0ELi4ELi2ELi4ELi7ELi17ELi2ELi1ELb0ELb1EE": (0, 2),      # 256 x 224
-        "ILb0ELi4ELi2ELi4ELi7ELi17ELi2ELi1ELb0ELb0EE": (0, 2),
-        "ILb0ELi2ELi4ELi4ELi3ELi26ELi4ELi1ELb0ELb1EE": (0, 4),      # 128 x 192
-        "ILb0ELi2ELi4ELi4ELi2ELi28ELi4ELi1ELb0ELb1EE": (0, 4),      # 128 x 128
-        "ILb0ELi2ELi4ELi4ELi2ELi28ELi4ELi1ELb1ELb0EE": (0, 4),      # 128 x 128 split-K
-        "ILb0ELi2ELi4ELi4ELi4ELi26ELi2ELi1ELb1ELb0EE": (0, 2),      # 128 x 256 in-launch pair split (one workgroup per CU)
+        "ILb0ELi2ELi4ELi4ELi4ELi26ELi4ELi1ELb0ELb1ELb0EE": (0, 4),      # 128 x 256, two workgroups per CU: the roofline kernel
+        "ILb0ELi2ELi4ELi4ELi4ELi26ELi4ELi1ELb0ELb0ELb0EE": (0, 4),
+        "ILb0ELi2ELi4ELi4ELi4ELi27ELi4ELi2ELb0ELb1ELb0EE": (0, 4),      # 128 x (16 x 16) 2-D tile (152 x 152 layers)
+        "ILb0ELi2ELi4ELi4ELi4ELi27ELi4ELi2ELb0ELb0ELb0EE": (0, 4),
+        "ILb0ELi2ELi4ELi8ELi4ELi26ELi2ELi1ELb0ELb1ELb0EE": (0, 2),      # 256 x 256
+        "ILb0ELi4ELi2ELi4ELi7ELi17ELi2ELi1ELb0ELb1ELb0EE": (0, 2),      # 256 x 224
+        "ILb0ELi4ELi2ELi4ELi7ELi17ELi2ELi1ELb0ELb0ELb0EE": (0, 2),
+        "ILb0ELi2ELi4ELi4ELi3ELi26ELi4ELi1ELb0ELb1ELb0EE": (0, 4),      # 128 x 192
+        "ILb0ELi2ELi4ELi4ELi2ELi28ELi4ELi1ELb0ELb1ELb0EE": (0, 4),      # 128 x 128
+        "ILb0ELi2ELi4ELi4ELi2ELi28ELi4ELi1ELb1ELb0ELb0EE": (0, 4),      # 128 x 128 split-K
+        "ILb0ELi2ELi4ELi4ELi4ELi26ELi2ELi1ELb1ELb0ELb0EE": (0, 2),      # 128 x 256 in-launch pair split (one workgroup per CU)
+        "ILb0ELi2ELi4ELi4ELi4ELi27ELi4ELi2ELb0ELb1ELb1EE": (0, 4),      # 2-D 128 x 256 + the back-to-back 1x1
     }
     seen = 0
     for name, r in rows.items():

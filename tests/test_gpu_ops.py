@@ -416,6 +416,51 @@ def test_every_dma_tile_config(tile):
     assert "conv_igemm_dma" in names
 
 
+@pytest.mark.parametrize("case", ["residual_block_3x3", "stride2_into_stage", "default_rules_152"])
+def test_back_to_back_1x1_fusion(case, monkeypatch):
+    """conv_common.h: conv_epilogue_fused_1x1 -- the 1x1 128 -> 64 conv behind a conv whose workgroups hold all 128 couts of their 256
+    positions is computed by that launch (second MFMA pass over the epilogue's fp16 values through LDS), no launch of its own:
+    Darknet-53's two sites at 152 x 152 (net/v3.py:16-19, 26-29): the residual block's 3x3 64 -> 128 + shortcut on the 2-D tap tile
+    (partial tiles in both directions, several images) and the stride-2 conv 64 -> 128 into the stage on the LDS-DMA tile (M tail).
+    Against the oracle, against the unfused plan of the same graph (YOLO_NO_FUSE2), and -- third case -- at the size where the
+    default tile rules pick the fusing tile by themselves."""
+    if case == "stride2_into_stage":
+        B, H, W, tile = 3, 44, 58, 6
+        g = new_graph(H, W, 64)
+        g.append(PL.conv2d_bn_act(g[-1].out, 128, 3, 2))            # 1: the host (no residual)
+        g.append(PL.conv2d_bn_act(g[-1].out, 64, 1, 1))             # 2: computed by 1
+        g.append(PL.conv2d_bn_act(g[-1].out, 128, 3, 1))            # 3
+        g.append(PL.shortcut(g[-1].out, g[1].out))                  # 4: y of layer 1 is still needed
+        cin = 64
+    else:
+        B, H, W, tile = (3, 37, 50, 12) if case == "residual_block_3x3" else (12, 152, 152, None)
+        g = new_graph(H, W, 32)
+        g.append(PL.conv2d_bn_act(g[-1].out, 128, 3, 1))            # 1: x
+        g.append(PL.conv2d_bn_act(g[-1].out, 64, 1, 1))             # 2
+        g.append(PL.conv2d_bn_act(g[-1].out, 128, 3, 1))            # 3: the host ...
+        g.append(PL.shortcut(g[-1].out, g[1].out))                  # 4: ... with its residual
+        g.append(PL.conv2d_bn_act(g[-1].out, 64, 1, 1))             # 5: computed by 3
+        g.append(PL.conv2d_bn_act(g[-1].out, 128, 3, 1))            # 6
+        g.append(PL.shortcut(g[-1].out, g[4].out))                  # 7
+        cin = 32
+    x = synth.synthetic_input(B, H, W, cin, seed=55)
+    eng = check_graph(g, x, "fp16", seed=14, tile=tile)
+    names = [ki.name.decode() for ki in eng.kernel_infos()]
+    syms = [ki.symbol.decode() for ki in eng.kernel_infos()]
+    assert sum("+1x1" in n for n in names) == 1 and sum("fused into the conv in front" in n for n in names) == 1, names
+    host = next(i for i, n in enumerate(names) if "+1x1" in n)
+    assert "fused into the conv in front" in names[host + 1] and syms[host + 1] == ""
+    assert ("conv_igemm_dma_kernel<2, 4, 4, 4, 3, 4, 4, true>" if case == "stride2_into_stage" else
+            "conv3x3_tap_kernel<false, 2, 4, 4, 4, 27, 4, 2, false, true, true>") in syms[host], syms[host]
+    fused = eng.forward(x).cpu().numpy()
+    assert np.array_equal(fused, eng.forward(x).cpu().numpy())
+    assert np.array_equal(fused[:1], eng.forward(x[:1]).cpu().numpy()[:1]) or tile is None      # (a forced tile also fuses at batch 1)
+    monkeypatch.setenv("YOLO_NO_FUSE2", "1")
+    plain, eng_p = run_hip(g, synth.darknet_stream(g, seed=14), x, "fp16", force_tile=tile)
+    assert not any("+1x1" in ki.name.decode() for ki in eng_p.kernel_infos()) and eng_p.num_kernels == eng.num_kernels
+    assert rel_err(fused, plain) <= 2e-3       # same products; only the K order of the 1x1's 128-deep sum differs
+
+
 @pytest.mark.parametrize("dtype,shape", [("fp16", (24, 13, 13, 256, 512)), ("fp16", (20, 19, 19, 512, 256)),
                                          ("fp32", (24, 13, 13, 128, 512)), ("fp32", (24, 19, 19, 128, 256))])
 def test_in_launch_pair_split_k(dtype, shape):
@@ -438,7 +483,7 @@ def test_in_launch_pair_split_k(dtype, shape):
     syms = [ki.symbol.decode() for ki in infos]
     pair = [i for i, n in enumerate(names) if "+pairK" in n]
     assert len(pair) == 2, names
-    want_sym = "conv3x3_tap_kernel<false, 2, 4, 4, 4, 26, 2, 1, true, false>" if dtype == "fp16" else "conv3x3_tap_kernel<true, 2, 4, 4, 2, 28, 4, 1, true, false>"
+    want_sym = "conv3x3_tap_kernel<false, 2, 4, 4, 4, 26, 2, 1, true, false, false>" if dtype == "fp16" else "conv3x3_tap_kernel<true, 2, 4, 4, 2, 28, 4, 1, true, false, false>"
     assert all(want_sym in syms[i] for i in pair), syms
     a = eng.forward(x).cpu().numpy()
     b = eng.forward(x).cpu().numpy()
