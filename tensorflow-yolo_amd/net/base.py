@@ -180,14 +180,15 @@ def _label_font():
     return _LABEL_FONT
 
 
-def draw_boxes(path_to_img, boxes, class_names):
+def draw_boxes(path_to_img, boxes, class_names, rgb=None):
     """Rectangles + "name prob" labels as the reference draws them (net/base.py:212-226): corners scaled by the ORIGINAL image
     size and clamped at 0 only, colour COLORS[class_idx % 6], `cv2.rectangle(..., thickness=3)` = a 3-pixel outline CENTRED on
     the corner coordinates (one pixel either side), label with its BASELINE's left end at (tl.x, tl.y - 10) -- so a box at the
     top edge loses its label, as there.  Pillow rasteriser (OpenCV is absent: glyph shapes differ, geometry does not).
-    Returns a PIL image."""
+    rgb: the image already decoded (uint8 [H,W,3], what decode_image returns) -- the pipelined test loop does not read and
+    decode every file twice; same pixels.  Returns a PIL image."""
     from PIL import Image, ImageDraw
-    image = Image.open(path_to_img).convert("RGB")
+    image = Image.open(path_to_img).convert("RGB") if rgb is None else Image.fromarray(rgb, "RGB")
     w, h = image.size
     draw = ImageDraw.Draw(image)
     font = _label_font()
@@ -211,5 +212,20 @@ def draw_boxes(path_to_img, boxes, class_names):
 def save_image(image, out_path):
     out_dir = os.path.dirname(out_path)
     if out_dir and not os.path.isdir(out_dir):
-        os.makedirs(out_dir)
-    image.save(out_path)
+        os.makedirs(out_dir, exist_ok=True)
+    if out_path.lower().endswith(".png"):       # cv2.imwrite's default PNG setting (IMWRITE_PNG_COMPRESSION = 1), not Pillow's 6: same
+        image.save(out_path, compress_level=1)  # pixels, a fifth of the encode time
+    else:
+        image.save(out_path)
+
+
+def draw_save_task(path, rgb, records, class_names, out_dir):
+    """One image of the test loop's last stage (reference net/yolo.py:88-95) as a task for a worker PROCESS of the pipelined loop
+    (drawing holds the GIL: threads do not scale): records [(x, y, w, h, class_idx, prob)] -> boxes drawn on the decoded pixels ->
+    `<stem>_out<ext>` written.  Touches neither torch nor the GPU.  Returns the console line."""
+    boxes = [BoundingBox(r[0], r[1], r[2], r[3], 0, 0, r[4], r[5]) for r in records]
+    new_img = draw_boxes(path, boxes, class_names, rgb=rgb)
+    file_name, file_ext = os.path.splitext(os.path.basename(path))
+    out_path = os.path.join(out_dir, "{}_out{}".format(file_name, file_ext))
+    save_image(new_img, out_path)
+    return "{}: Found {} objects. Saved to {}".format(file_name, len(boxes), out_path)
