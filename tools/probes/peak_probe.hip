@@ -104,6 +104,59 @@ __global__ void __launch_bounds__(256) read_kernel(const float4v *__restrict__ i
 
 static double elapsed_ms(hipEvent_t a, hipEvent_t b) { float ms = 0.f; CHECK(hipEventElapsedTime(&ms, a, b)); return ms; }
 
+// LDS-fed loop with a TM x TP fragment tile per wave (TM + TP ds_read_b128 per TM * TP MFMAs) and WAVES waves per workgroup:
+// what register tile / occupancy combination an LDS-fed conv loop should aim for.
+template <int TM, int TP, int WAVES, int OCC>
+__global__ void __launch_bounds__(WAVES * 64, OCC) mfma_f16_tile_kernel(const half8 *src, float *sink, int iters) {
+    __shared__ half8 lds[2048];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 2048; i += WAVES * 64) lds[i] = src[i];
+    __syncthreads();
+    float4v acc[TM][TP];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+        half8 a[TM], b[TP];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = lds[(lane + 64 * i + it * 7) & 2047];
+#pragma unroll
+        for (int j = 0; j < TP; ++j) b[j] = lds[(lane + 64 * (j + TM) + it * 13) & 2047];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (s == 123.456f) sink[threadIdx.x] = s;
+}
+
+template <int TM, int TP, int WAVES, int OCC>
+static double run_tile(const half8 *src, float *sink, int grid, double min_seconds) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const int iters = 170 * 16 / (TM * TP) * 16 / WAVES * 512 / grid;     // ~ the same flops per launch as the 4 x 4 / 8-wave / 512-workgroup run
+    int reps = 50;
+    for (;;) {
+        CHECK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((mfma_f16_tile_kernel<TM, TP, WAVES, OCC>), dim3(grid), dim3(WAVES * 64), 0, 0, src, sink, iters);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        if (elapsed_ms(e0, e1) * 1e-3 >= min_seconds) break;
+        reps *= 2;
+    }
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((mfma_f16_tile_kernel<TM, TP, WAVES, OCC>), dim3(grid), dim3(WAVES * 64), 0, 0, src, sink, iters);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    const double ms = elapsed_ms(e0, e1) / reps;
+    return (double)grid * WAVES * iters * (double)(TM * TP) * (2.0 * 16 * 16 * 32) / (ms * 1e-3) / 1e12;
+}
+
+
 template <bool LDS>
 static void run_f16(const half8 *src, float *sink, unsigned long long *clk, int grid, int iters, double min_seconds, double &tflops, double &ghz, double &us) {
     hipEvent_t e0, e1;
@@ -144,6 +197,12 @@ int main() {
     double tf_rand, ghz_rand, us_rand, tf_lds, ghz_lds, us_lds, tf_zero, ghz_zero, us_zero;
     run_f16<false>(src, sink, clk, grid, 170, 1.5, tf_rand, ghz_rand, us_rand);
     run_f16<true>(src, sink, clk, grid, 170, 1.5, tf_lds, ghz_lds, us_lds);
+    // register tile / occupancy variants of the LDS-fed loop (random operands)
+    const double t44_16 = run_tile<4, 4, 8, 4>(src, sink, 512, 1.0);      // 4 x 4 tile, 16 waves per CU (the tap kernel's shape)
+    const double t84_8 = run_tile<8, 4, 8, 2>(src, sink, 256, 1.0);       // 8 x 4 tile, one 8-wave workgroup per CU
+    const double t84_2x4 = run_tile<8, 4, 4, 2>(src, sink, 512, 1.0);     // 8 x 4 tile, two 4-wave workgroups per CU
+    const double t48_2x4 = run_tile<4, 8, 4, 2>(src, sink, 512, 1.0);     // 4 x 8
+    const double t47_8 = run_tile<4, 7, 8, 2>(src, sink, 256, 1.0);       // 4 x 7 (the 19 x 19 tile)
     CHECK(hipMemset(src, 0, 4096 * sizeof(half8)));
     run_f16<false>(src, sink, clk, grid, 170, 1.5, tf_zero, ghz_zero, us_zero);
     // fp32 MFMA
@@ -178,9 +237,10 @@ int main() {
            "\"mfma_f16_lds_fed_tflops\": %.1f, \"mfma_f16_lds_fed_clock_ghz\": %.3f, "
            "\"mfma_f16_zero_operands_tflops\": %.1f, \"mfma_f16_zero_operands_clock_ghz\": %.3f, "
            "\"mfma_f32_tflops_sustained\": %.1f, \"hbm_copy_tb_s\": %.2f, \"hbm_read_tb_s\": %.2f, "
+           "\"lds_fed_tile_variants_tflops\": {\"4x4_16waves\": %.1f, \"8x4_8waves_1wg\": %.1f, \"8x4_2x4waves\": %.1f, \"4x8_2x4waves\": %.1f, \"4x7_8waves_1wg\": %.1f}, "
            "\"note\": \"tools/probes/peak_probe.hip: v_mfma_f32_16x16x32_f16 on random register operands, 8 waves x 2 workgroups per CU, 16 accumulators per wave, "
            "launches of ~100 us back to back for >= 1.5 s (the clock the chip holds under matrix load); lds_fed = operands re-read from LDS at the tap kernel's "
            "ratio; zero_operands = the same loop on zeros (no data-dependent power); float4 copy of 1 GiB (read + write bytes / time) and read-only sweep of 1 GiB\"}\n",
-           prop.name, prop.multiProcessorCount, tf_rand, ghz_rand, us_rand, tf_lds, ghz_lds, tf_zero, ghz_zero, tf32, tbs, tbs_rd);
+           prop.name, prop.multiProcessorCount, tf_rand, ghz_rand, us_rand, tf_lds, ghz_lds, tf_zero, ghz_zero, tf32, tbs, tbs_rd, t44_16, t84_8, t84_2x4, t48_2x4, t47_8);
     return 0;
 }
