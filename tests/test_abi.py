@@ -51,6 +51,15 @@ def test_plan_yolov3_608():
     assert p.workspace_bytes < 4 << 30
     # activation buffers are reused: far less than the sum of all layer outputs (17 GB at b32)
     assert p.workspace_bytes < 2.5e9
+    # round 4: the two 1x1 128 -> 64 convs at 152 x 152 are marked for the back-to-back fusion with the conv in front of them
+    assert d.count("computed by the conv in front of it") == 2
+    # ... and the library's own stream rule (yolo_net_options.streams = 0): two half batches for this net from batch 16 up, fp16 only
+    assert p.num_streams == 2
+    assert engine.Plan(net, dtype="fp16", max_batch=16).num_streams == 2 and engine.Plan(net, dtype="fp16", max_batch=8).num_streams == 1
+    assert engine.Plan(net, dtype="fp32", max_batch=32).num_streams == 1
+    assert engine.Plan(net, dtype="fp16", max_batch=32, streams=1).num_streams == 1 and engine.Plan(net, dtype="fp16", max_batch=8, streams=2).num_streams == 2
+    net416 = v3.create_network(np.reshape(cases.COCO_V3_ANCHORS, [-1, 2]), NAMES80, False, input_shape=(416, 416, 3))
+    assert engine.Plan(net416, dtype="fp16", max_batch=32).num_streams == 2 and engine.Plan(net416, dtype="fp16", max_batch=16).num_streams == 1
 
 
 def test_plan_yolov2_and_tiny():
@@ -60,6 +69,7 @@ def test_plan_yolov2_and_tiny():
     assert p.num_kernels == 23 + 3                  # convs, pools (the first two pools are taken inside the convs in front of them:
                                                     # conv_first_pool and the 208 x 208 64-cout 2-D tap tile); input cast, reorg and routes are free
     assert engine.Plan(net, dtype="fp16", max_batch=16).num_kernels == 23 + 2      # fp16: the 104 x 104 128-cout conv takes its pool too
+    assert engine.Plan(net, dtype="fp16", max_batch=64).num_streams == 1            # Darknet-19 is a short chain: one stream whatever the batch
     d = p.describe()
     assert "fused: reorg x2" in d and d.count("concat slice") == 2
     tiny = v2.create_tiny_network(np.reshape(cases.VOC_TINY_ANCHORS, [-1, 2]), NAMES80[:20], False)
