@@ -408,7 +408,9 @@ def main():
                        "global_batch": batch * world, "weights": "seeded synthetic Darknet stream (random-init)",
                        "threshold": args.threshold, "iou_threshold": args.iou_threshold, "streams": int(eng.num_streams),
                        "streams_rule": "explicit --streams %d" % args.streams if args.streams > 0 else
-                                       "yolo_net_options.streams = 0: the library's rule (DESIGN.md, Kernel boundaries)",
+                                       "yolo_net_options.streams = 0: the library's rule%s (DESIGN.md, Kernel boundaries)" %
+                                       (", then one pass vs two halves timed on this device at the first batch (yolo_net_tune_streams)"
+                                        if getattr(eng, "_streams_tuned", False) else ""),
                        "sharding": "images over ranks; all-gather of box records only" if world > 1 else "single GPU",
                        "boxes_per_image_last_step": round(float(nboxes.mean()), 1),
                        "forward_gflop_per_image": round(eng.flops_per_image / 1e9, 3)},

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define YOLO_HIP_ABI_VERSION 3      /* 2: yolo_kernel_info.symbol; 3: yolo_net_num_streams, streams = 0 is the library's rule */
+#define YOLO_HIP_ABI_VERSION 4      /* 2: yolo_kernel_info.symbol; 3: yolo_net_num_streams, streams = 0 is the library's rule; 4: yolo_net_tune_streams */
 
 enum yolo_status {
     YOLO_OK = 0,
@@ -90,7 +90,8 @@ typedef struct yolo_net_options {
                              * parts on the caller's + internal streams (overlaps the kernels' tails and launch
                              * boundaries); 0: the library's rule (two parts for fp16 nets of >= 40 conv launches
                              * whose half batch is >= 2.5 M input pixels, e.g. YOLOv3-608 at batch >= 16, else one;
-                             * the environment variable YOLO_STREAMS overrides the rule).  Results do not depend on it.
+                             * the environment variable YOLO_STREAMS overrides the rule; yolo_net_tune_streams() re-measures
+                             * the rule's "two" on the device).  Results do not depend on it up to fp16 summation order.
                              * yolo_net_num_streams() tells what a net runs with.                              */
     int32_t force_tile;     /* 0: per-layer tile choice (cost model / autotune); t + 1: run conv tile id t on every
                              * conv layer that accepts it (0 = 4-wave kernel, 1-7 and 14 LDS-DMA tiles, 8-13 and 15-17
@@ -134,7 +135,12 @@ int yolo_net_head_desc(const yolo_net *net, yolo_head_desc *out);
  * net/v2.py:83-85) get their head geometry from the caller before detect() */
 int yolo_net_set_head(yolo_net *net, const yolo_head_desc *head);
 int yolo_net_num_kernels(const yolo_net *net);
-int yolo_net_num_streams(const yolo_net *net);      /* parts / HIP streams a full batch runs as (yolo_net_options.streams)   */
+int yolo_net_num_streams(const yolo_net *net);      /* parts / HIP streams a full batch currently runs as (yolo_net_options.streams) */
+/* Where streams = 0 picked two halves by rule, both activation arenas hold a FULL batch and this call (optional, once, with a batch
+ * above max_batch / 2; synchronous, 30 forward passes) times one pass against two halves on THIS device and keeps two halves where they win by 1.5 %: the same
+ * build gains 3-4 % from two halves on one MI355X and loses 1-2 % on another (power-limited clocks differ from board to board).
+ * No-op for nets whose streams were given explicitly or whose rule says one.  The Python engine calls it at its first full batch. */
+int yolo_net_tune_streams(yolo_net *net, const float *in_dev, int batch, void *stream);
 /* human-readable plan (kernels, fusions, buffers); returns bytes needed incl. NUL */
 size_t yolo_net_describe(const yolo_net *net, char *buf, size_t cap);
 

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # enum yolo_op
 OP_INPUT, OP_CONV, OP_MAXPOOL, OP_ROUTE, OP_REORG, OP_SHORTCUT, OP_UPSAMPLE, OP_YOLO, OP_DETECTION = range(9)
@@ -74,6 +74,7 @@ SIGNATURES = {
     "yolo_net_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "yolo_net_autotune": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "yolo_net_tune_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "yolo_net_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(KernelInfo)]),
     "yolo_net_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "yolo_net_read_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),

@@ -25,6 +25,8 @@ static int fail(int code, const std::string &msg) {
 }
 
 namespace {
+// images one part of a full batch holds (what every launch of a forward pass sees at most)
+inline int part_batch(const yolo_net *net) { return (net->opt.max_batch + net->parts - 1) / net->parts; }
 const size_t kPairCounterBytes = 16384;            // in-launch pair split (conv_tap.hip): one int per tile, in front of the slabs
 bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile);
 size_t splitk_slab_bytes(const yolo_net *net);
@@ -95,7 +97,7 @@ size_t yolo_net_workspace_bytes(const yolo_net *net) { return net ? net->workspa
 size_t yolo_net_output_count(const yolo_net *net) { return net ? net->out_count : 0; }
 double yolo_net_flops_per_image(const yolo_net *net) { return net ? net->flops_per_image : 0.0; }
 int yolo_net_num_kernels(const yolo_net *net) { return net ? (int)net->kernels.size() : 0; }
-int yolo_net_num_streams(const yolo_net *net) { return net ? net->arenas : 0; }
+int yolo_net_num_streams(const yolo_net *net) { return net ? net->parts : 0; }
 
 int yolo_net_head_desc(const yolo_net *net, yolo_head_desc *out) {
     if (!net || !out) return fail(YOLO_ERR_ARG, "yolo_net_head_desc: null argument");
@@ -375,7 +377,7 @@ void conv_shape_params(const yolo_net *net, const Kernel &k, int batch, ConvPara
 // float32 partial-sum slab one arena needs for ANY batch up to its share of max_batch (a net built for batch 32 also runs
 // the short last batch of a TEST directory, where the small maps do split): 0 when no launch ever splits
 size_t splitk_slab_bytes(const yolo_net *net) {
-    const int per = (net->opt.max_batch + net->arenas - 1) / net->arenas;
+    const int per = net->arena_full ? net->opt.max_batch : (net->opt.max_batch + net->arenas - 1) / net->arenas;
     size_t need = 0;
     for (const Kernel &k : net->kernels) {
         if (k.kind != K_CONV || k.stem >= 2) continue;
@@ -499,7 +501,7 @@ int run_forward_pass(yolo_net *net, const float *in_dev, int batch, float *out_d
                     p.out3 = P.view_ptr(t.out);
                     p.out3_ld = t.out.ld; p.out3_img_stride = t.out.img_stride;
                 }
-                e = launch_stem(p, batch, s, net->halves ? 512 / net->arenas : 512);
+                e = launch_stem(p, batch, s, net->halves ? 512 / net->parts : 512);
                 break;
             }
             if (k.stem == 3) break;     // computed by the stem kernel
@@ -588,8 +590,8 @@ int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, h
 }
 int run_forward_impl(yolo_net *net, const float *in_dev, int batch, float *out_dev, hipStream_t s, hipEvent_t *ev) {
     const long long rows = net->head.n_classes > 0 ? (long long)(net->out_count / (size_t)(5 + net->head.n_classes)) : -1;
-    const int parts = net->arenas;
-    const int per = (net->opt.max_batch + parts - 1) / parts;       // images an arena holds
+    const int parts = net->parts;
+    const int per = (net->opt.max_batch + parts - 1) / parts;       // images a part holds
     if (parts >= 2 && batch > per) {
         if (ev) return fail(YOLO_ERR_STATE, "per-kernel events need the parts timed one by one (yolo_net_forward_timed)");
         if (net->side.empty()) {
@@ -702,7 +704,7 @@ int yolo_net_forward_timed(yolo_net *net, const float *in_dev, int batch, float 
         if (hipEventCreate(&e) != hipSuccess) return fail(YOLO_ERR_HIP, "hipEventCreate failed");
     // with several arenas the parts are timed one after the other on the caller's stream (each kernel alone on the chip)
     // and their times added per kernel
-    const int parts = net->arenas;
+    const int parts = net->parts;
     const int per = (net->opt.max_batch + parts - 1) / parts;
     const yolo_layer_desc &d0 = net->layers[0].d;
     const size_t in_img = (size_t)d0.h * d0.w * d0.c;
@@ -767,7 +769,7 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
         }
         // which kernel runs at max_batch (bench.py runs at max_batch): the same decision the launch path takes
         ConvParams sp;
-        const int per_arena = (net->opt.max_batch + net->arenas - 1) / net->arenas;
+        const int per_arena = part_batch(net);
         conv_shape_params(net, k, per_arena, sp);
         const size_t slab_i = net->splitk_bytes / (size_t)net->arenas / 256 * 256;
         const size_t slab_d = slab_i > kPairCounterBytes ? slab_i - kPairCounterBytes : 0;
@@ -849,13 +851,46 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
     return YOLO_OK;
 }
 
+int yolo_net_tune_streams(yolo_net *net, const float *in_dev, int batch, void *stream) {
+    int rc = check_ready(net, in_dev, batch, "yolo_net_tune_streams");
+    if (rc) return rc;
+    if (!net->arena_full || batch <= (net->opt.max_batch + 1) / 2) return YOLO_OK;       // nothing to choose (or not with this batch)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float *logits = reinterpret_cast<float *>(net->dev_ws + net->logits_off);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    // interleaved: one pass, two halves, one pass, ... -- three forward passes per sample, the first round of each only warms up,
+    // the best of the other four counts (boxes differ: the same build gains 3-4 % from two halves on one MI355X and loses 1-2 % on
+    // another, so the rule's answer is re-measured where the net runs)
+    float best[3] = {0.f, 1e30f, 1e30f};
+    for (int rep = 0; rep < 5 && rc == YOLO_OK; ++rep)
+        for (int parts = 1; parts <= 2 && rc == YOLO_OK; ++parts) {
+            net->parts = parts;
+            if (hipEventRecord(e0, s) != hipSuccess) rc = fail(YOLO_ERR_HIP, "yolo_net_tune_streams: hipEventRecord failed");
+            for (int k = 0; k < 3 && rc == YOLO_OK; ++k) rc = run_forward(net, in_dev, batch, logits, s);
+            if (rc == YOLO_OK && (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess))
+                rc = fail(YOLO_ERR_HIP, "yolo_net_tune_streams: event failed");
+            float ms = 0.f;
+            if (rc == YOLO_OK && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && rep > 0 && ms < best[parts]) best[parts] = ms;
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    // two halves must win by 1.5 %: where they do not gain 3-4 % they are within +-1 % of one pass, which the later steady state
+    // (warmer chip, decode + NMS behind the join) has been seen to turn into a loss
+    net->parts = (rc == YOLO_OK && best[2] < 0.985f * best[1]) ? 2 : (rc == YOLO_OK ? 1 : net->arenas);
+    net->parts_tuned = rc == YOLO_OK;
+    net->obj_valid = false;
+    return rc;
+}
+
 int yolo_net_autotune(yolo_net *net, const float *in_dev, int batch, void *stream) {
     int rc = check_ready(net, in_dev, batch, "yolo_net_autotune");
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     float *logits = reinterpret_cast<float *>(net->dev_ws + net->logits_off);
     {   // every launch of a multi-stream net sees one part of the batch: tune for that size (arena 0)
-        const int per = (net->opt.max_batch + net->arenas - 1) / net->arenas;
+        const int per = part_batch(net);
         if (batch > per) batch = per;
     }
     rc = run_forward(net, in_dev, batch, logits, s);      // real activations in every buffer

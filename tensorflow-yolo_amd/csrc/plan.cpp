@@ -601,6 +601,7 @@ struct Planner {
         // tiny-YOLOv2 b64 float32 -0.5 %): fp16, >= 40 conv launches, >= 2.5 M input pixels per part.
         {
             int want = net->opt.streams > 0 ? net->opt.streams : (getenv("YOLO_STREAMS") ? atoi(getenv("YOLO_STREAMS")) : 0);
+            const bool by_rule = want <= 0;
             if (want <= 0) {
                 int convs = 0;
                 for (const Kernel &k : K) convs += k.kind == K_CONV && k.stem < 3;
@@ -610,8 +611,12 @@ struct Planner {
             }
             net->arenas = (want >= 2 && !net->opt.keep_all) ? (want > 4 ? 4 : want) : 1;
             if (net->arenas > net->opt.max_batch) net->arenas = net->opt.max_batch;
+            // by rule: both arenas hold a full batch (twice the activation memory: 3 GB for YOLOv3-608 b32), so that the choice between
+            // one pass and two halves can be made -- and changed -- per device (yolo_net_tune_streams)
+            net->arena_full = by_rule && net->arenas == 2;
+            net->parts = net->arenas;
         }
-        const int arena_batch = (net->opt.max_batch + net->arenas - 1) / net->arenas;
+        const int arena_batch = net->arena_full ? net->opt.max_batch : (net->opt.max_batch + net->arenas - 1) / net->arenas;
         for (Buffer &b : B) b.bytes = roundup_sz((size_t)b.elems_per_image * b.esize * arena_batch + 256, align);
         size_t top = 0;
         if (net->opt.keep_all) {

@@ -356,6 +356,12 @@ struct yolo_net {
     hipEvent_t e_fork = nullptr;
     std::vector<hipEvent_t> e_join;
     int arenas = 1;                        // activation arenas (2: one per half batch)
+    // streams = 0 picked two parts by rule: every arena is then planned for the FULL batch, so that the same net can also run one pass
+    // on one stream, and `parts` (1 or 2) says what a forward does -- the rule's answer until yolo_net_tune_streams has timed both
+    // on this device (two halves gain 3-4 % on some MI355X and lose 1-2 % on others: profiles/r04_ablation.md section 7)
+    bool arena_full = false;
+    int parts = 1;                         // parts a full batch currently runs as (== arenas unless arena_full)
+    bool parts_tuned = false;
     size_t arena_bytes = 0;
     bool halves = false;                   // the current forward runs as two concurrent half-batch passes
     size_t workspace_bytes = 0;

@@ -97,7 +97,8 @@ class Plan(object):
         self.output_count = self.lib.yolo_net_output_count(handle)
         self.flops_per_image = self.lib.yolo_net_flops_per_image(handle)
         self.num_kernels = self.lib.yolo_net_num_kernels(handle)
-        self.num_streams = self.lib.yolo_net_num_streams(handle)       # parts a full batch runs as (streams=0: the library's rule)
+        self._auto_streams = int(streams) <= 0                          # streams = 0: the library's rule, re-measured on the device
+        self._streams_tuned = False                                     # (HipNetwork: at the first full batch)
         self.input_hwc = self.layers[0].out.hwc
         last = self.layers[-1]
         if isinstance(last, L.detection_layer):
@@ -105,6 +106,12 @@ class Plan(object):
             self.set_head(head_desc_v3(last.yolos))
         else:
             self.output_shape = last.out.hwc                                    # [h, w, c]
+
+    @property
+    def num_streams(self):
+        """parts / HIP streams a full batch currently runs as (yolo_net_options.streams; 0 = the library's rule, which a
+        HipNetwork re-measures on the device at its first full batch: yolo_net_tune_streams)"""
+        return self.lib.yolo_net_num_streams(self.handle)
 
     def set_head(self, hd):
         _hip.check(self.lib.yolo_net_set_head(self.handle, C.byref(hd)), "yolo_net_set_head")
@@ -176,10 +183,23 @@ class HipNetwork(Plan):
             raise ValueError("batch %d outside 1..%d (max_batch)" % (x.shape[0], self.max_batch))
         return x
 
+    def _tune_streams(self, x):
+        """streams = 0 and the rule said two halves: time one pass against two halves on THIS device, once, with the first batch
+        that is large enough, and keep the faster (yolo_net_tune_streams: the gain is board-dependent, +4 % to -1.5 %)."""
+        if self._streams_tuned or not self._auto_streams or not self.weights_loaded:
+            return
+        if self.lib.yolo_net_num_streams(self.handle) < 2 or 2 * x.shape[0] <= self.max_batch:
+            self._streams_tuned = self.lib.yolo_net_num_streams(self.handle) < 2
+            return
+        with self.torch.cuda.device(self.device):
+            _hip.check(self.lib.yolo_net_tune_streams(self.handle, x.data_ptr(), x.shape[0], self._stream()), "yolo_net_tune_streams")
+        self._streams_tuned = True
+
     def forward(self, x, out=None):
         """Head logits (float32, device) in the reference's layout: v2 [B,h,w,A*(5+C)], v3 [B,rows,5+C]."""
         torch = self.torch
         x = self.to_device(x)
+        self._tune_streams(x)
         b = x.shape[0]
         if out is None:
             out = torch.empty((b,) + tuple(self.output_shape), dtype=torch.float32, device=self.device)
@@ -193,6 +213,7 @@ class HipNetwork(Plan):
         (x,y,w,h,prob,class-as-int32-bits), counts [B], status [B]); no host sync."""
         torch = self.torch
         x = self.to_device(x)
+        self._tune_streams(x)
         b = x.shape[0]
         with torch.cuda.device(self.device):
             _hip.check(self.lib.yolo_net_detect(self.handle, x.data_ptr(), b, float(threshold), float(iou_threshold),
