@@ -264,6 +264,7 @@ bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile) {
     if (k.outmode == OUT_POOL2 && tile != 12 && tile != 13 && tile != 17) return false;      // the fused max-pool lives in the 16 x 16 2-D tap tiles
     if (tile == 0) return true;
     if (net->opt.dtype == YOLO_DTYPE_F32 && !dma_cfg_f32_ok(tile)) return false;
+    if (tile == 18 && k.in.H != k.in.W) return false;     // the image-aligned tap tile: square maps (the rules price tiles by W alone)
     return dma_eligible(net, k) && dma_cfg_valid(tile, k.cout, k.cpt, true, k.ksize, k.stride, k.in.W);
 }
 
@@ -319,7 +320,10 @@ const size_t kSplitkSlabMax = (size_t)64 << 20;     // per arena
 ConvPick pick_conv(const yolo_net *net, const Kernel &k, const ConvParams &p, int tile_req, size_t slab_bytes) {
     int tile = tile_req;
     if (!dma_eligible(net, k) || (tile > 0 && !conv_tile_valid(net, k, tile))) tile = 0;
-    else if (tile < 0) tile = choose_dma_cfg(p.M, k.cout, k.cpt, p.taps, k.has_res, true, k.stride, k.in.W, net->opt.dtype == YOLO_DTYPE_F32);
+    else if (tile < 0) {
+        tile = choose_dma_cfg(p.M, k.cout, k.cpt, p.taps, k.has_res, true, k.stride, k.in.W, net->opt.dtype == YOLO_DTYPE_F32);
+        if (tile == 18 && !conv_tile_valid(net, k, 18)) tile = conv_tile_valid(net, k, 15) ? 15 : 8;
+    }
     int ku = 0;
     int ks = choose_ksplit(k, p, tile, slab_bytes, ku);
     // a 3x3/1 layer small enough for split-K runs it on the 128 x 128 tap tile (the one with the split-K instantiation), whatever

@@ -268,11 +268,12 @@ static const DmaCfg kCfgs[] = {
     {256, 224, 1, 1.00f, "256x224,tap9", 4},           // 15: conv_tap.hip variant 6 (see there)
     {128, 128, 3, 1.00f, "128x128,tap9,2d,x3", 4},     // 16: conv_tap.hip variant 7: 8 x 16 2-D tile, three workgroups per CU
     {32, 256, 2, 1.00f, "32x256,tap9,2d,x2", 4},       // 17: conv_tap.hip variant 8: 32 couts x (16 x 16)
+    {128, 384, 1, 1.00f, "128x384,tap9,img", 4},       // 18: conv_tap.hip variant 9: one whole image (19 x 19) per tile
 };
-static const int kNumCfgs = 18;
+static const int kNumCfgs = 19;
 static const int kFirstTapCfg = 8, kLastTapCfg = 13;
-static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || cfg == 15 || cfg == 16 || cfg == 17; }
-static inline int tap_variant(int cfg) { return cfg == 15 ? 6 : cfg == 16 ? 7 : cfg == 17 ? 8 : cfg - kFirstTapCfg; }     // conv_tap.hip variant of a tap cfg
+static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || (cfg >= 15 && cfg <= 18); }
+static inline int tap_variant(int cfg) { return cfg >= 15 ? cfg - 9 : cfg - kFirstTapCfg; }     // conv_tap.hip variant of a tap cfg
 bool dma_cfg_is_tap(int cfg) { return is_tap_cfg(cfg); }
 bool dma_cfg_f32_ok(int cfg) { return is_tap_cfg(cfg) && conv_tap_f32_ok(tap_variant(cfg)); }
 
@@ -318,6 +319,7 @@ static const TileCost kCost[] = {
     {1.05f, 1.05f, 1.05f, 18.0f},       // 15: 256x224 tap reuse (7/8 of the 256x256 tile's loop)
     {0.0f, 0.0f, 0.0f, 0.0f},           // 16: 128x128 2-D tap reuse, three per CU (chosen by rule)
     {0.0f, 0.0f, 0.0f, 0.0f},           // 17: 32x256 2-D tap reuse (chosen by rule)
+    {0.90f, 0.90f, 0.90f, 18.0f},       // 18: 128x384 image-aligned tap reuse (6/7 of the 256x224 tile's loop)
 };
 
 int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W, bool tap_only) {
@@ -372,7 +374,8 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
             if (conv_tap_is2d(tap_variant(c))) { const long long th = k.nb / 16, tx = (W + 15) / 16, ty = (W + th - 1) / th; Meff = (long long)M * tx * ty * k.nb / ((long long)W * W); }
             else Meff = (long long)M * (W + 1) * (W + 1) / ((long long)W * W);
         }
-        const long long blocks = (Meff + k.nb - 1) / k.nb * ((cout + k.na - 1) / k.na);
+        long long blocks = (Meff + k.nb - 1) / k.nb * ((cout + k.na - 1) / k.na);
+        if (is_tap_cfg(c) && conv_tap_image_aligned(tap_variant(c))) blocks = (long long)(M / (W * W)) * ((cout + k.na - 1) / k.na);    // a tile per image
         const long long slots = 256LL * k.slots_per_cu;     // resident workgroups on the chip
         // one workgroup per CU: whole rounds; two per CU: the dispatcher back-fills, the tail costs ~half a round
         double rounds, a;
@@ -481,7 +484,9 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
             p.qHW = (p.H + 1) * (p.W + 1);
             mq = (long long)(p.M / p.HoWo) * p.qHW;
         }
-        const long long qblocks = (mq + k.nb - 1) / k.nb * p.n_tiles_n;
+        const bool img = conv_tap_image_aligned(tap_variant(cfg));
+        p.q_stride = img ? p.qHW : k.nb;
+        const long long qblocks = img ? (long long)(p.M / p.HoWo) * p.n_tiles_n : (mq + k.nb - 1) / k.nb * p.n_tiles_n;
         if (qblocks <= 0 || qblocks > 0x7fffffffLL) return hipErrorInvalidValue;
         p.Mq = (int)mq;
         p.n_blocks = (int)qblocks;

@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     const int mt = (int)fdiv((uint32_t)bid, p.dtiles_n);
     const int nt = bid - mt * p.n_tiles_n;
     const int n0 = nt * NA;
-    const int q0 = mt * NB;
+    const int q0 = mt * p.q_stride;    // NB, or (H+1)(W+1) for the image-aligned tile (variant 9)
     const bool has_a = JA_TOT % NW == 0 || wave < JA_TOT;   // wave-uniform
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, p.in_bytes, 0x00020000);
@@ -639,10 +639,15 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_stream_kernel(const Conv
 // a workgroup spends as long in setup + epilogue as in its K loop (152 x 152 64 -> 128: block trace in profiles/r03_ablation.md)
 // 8 = 32 couts x (16 x 16): the one 3x3 layer with 32 filters behind the first conv (tiny-YOLOv2 16 -> 32 at 208 x 208; float32 MFMA is 1/16 of
 // fp16's, so the 64-cout tile's idle half would double a launch that is MFMA-bound)
-static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224, 128, 256};
-static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17, 12, 27};
-static const int kTapVariants = 9;
-static const bool kTapF32[] = {false, false, false, true, false, true, false, false, true};      // float32 tiles: TP <= 2 (second-level accumulator)
+// 9 = 128 couts x 384 positions, IMAGE-ALIGNED, one workgroup per CU: a tile is one whole image of a map with H (W+1) <= 384 (19 x 19:
+// 380), tile m starts at position m (H+1)(W+1) -- the shared pad row behind every image is never computed (6 % of the positions are
+// padding instead of 10.8 %) and 19 x 19 at batch 32 is 32 x 8 = 256 tiles: every CU busy, 14 % less work per CU than the 232 tiles
+// of variant 6
+static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224, 128, 256, 384};
+static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17, 12, 27, 27};
+static const int kTapVariants = 10;
+static const bool kTapF32[] = {false, false, false, true, false, true, false, false, true, false};      // float32 tiles: TP <= 2 (second-level accumulator)
+bool conv_tap_image_aligned(int variant) { return variant == 9; }
 bool conv_tap_splitk_ok(int variant) { return variant == 3; }      // the 128 x 128 tile has the (two-pass) split-K instantiation
 bool conv_tap_pair_ok(int variant, bool f32) { return variant == 3 || (variant == 0 && !f32); }   // in-launch pair split: also the fp16 128 x 256 tile
 bool conv_tap_is2d(int variant) { return variant == 4 || variant == 5 || variant == 7 || variant == 8; }
@@ -650,6 +655,8 @@ bool conv_tap_f32_ok(int variant) { return variant >= 0 && variant < kTapVariant
 bool conv_tap_fits(int variant, int W) {
     if (variant < 0 || variant >= kTapVariants) return false;
     if (conv_tap_is2d(variant)) return true;
+    // (the image-aligned tile: square maps of 17 .. 19 -- a whole image per tile with at least 80 % of the positions real)
+    if (conv_tap_image_aligned(variant) && (W * (W + 1) > kTapNB[variant] || W * (W + 1) * 5 < kTapNB[variant] * 4)) return false;
     return kTapNB[variant] + 2 * W + 4 <= kTapPRG[variant] * 16;
 }
 
@@ -664,7 +671,8 @@ bool conv_tap_fits(int variant, int W) {
     X(5, 1, 8, 4, 2, 27, 4, 2) \
     X(6, 4, 2, 4, 7, 17, 2, 1) \
     X(7, 2, 4, 4, 2, 12, 6, 2) \
-    X(8, 1, 8, 2, 2, 27, 4, 2)
+    X(8, 1, 8, 2, 2, 27, 4, 2) \
+    X(9, 2, 4, 4, 6, 27, 2, 1)
 
 const char *conv_tap_symbol(int variant, bool f32, bool fast) {
     switch (variant) {
@@ -721,6 +729,8 @@ hipError_t launch_conv_tap(const ConvParams &p0, int variant, hipStream_t s) {
     p.fast_epi = !no_fast_epi && conv_fast_epilogue_ok(p) ? 1 : 0;
     if (p.ksize != 3 || p.stride != 1 || p.pad != 1 || p.Ho != p.H || p.Wo != p.W || (p.cin_chunks & 3) || !conv_tap_fits(variant, p.W) ||
         (p.f32 && !conv_tap_f32_ok(variant)))
+        return hipErrorInvalidValue;
+    if (conv_tap_image_aligned(variant) ? (p.q_stride != p.qHW || p.H * (p.W + 1) > kTapNB[variant]) : (!conv_tap_is2d(variant) && p.q_stride != kTapNB[variant]))
         return hipErrorInvalidValue;
     if (p.outmode == OUT_POOL2 && ((variant != 4 && variant != 5 && variant != 8) || (p.H & 1) || (p.W & 1) || p.has_res || p.ksplit > 1 || !p.vec_out || p.Cout % 16))
         return hipErrorInvalidValue;        // the fused pool lives in the 2-D tiles' epilogue only (plan.cpp asks for it accordingly)

@@ -126,6 +126,7 @@ struct ConvParams {
     long long out2_img_stride;
     int dbg;                   // experiment flags (YOLO_CONV_DBG): 1 skip steady-state DMA, 2 skip MFMA phase
     int qW, qHW, Mq;           // conv_tap.hip: padded-linear pixel grid, row stride W+1, image stride (H+1)(W+1), total
+    int q_stride;              // conv_tap.hip MODE 1: first position of tile m = m * q_stride (positions per tile; qHW for the image-aligned tile)
     int t2_shift;              // conv_tap.hip MODE 2: log2 of the positions per 2-D tile (8: 16 x 16, 7: 8 x 16)
     float *obj_out;            // head convs (staged float32 epilogue): compact objectness logits [B][obj_rows] or null
     int obj_width, obj_rows, obj_row0, obj_na;     // 5 + classes; rows per image; first row of this scale; anchors per cell
@@ -274,6 +275,7 @@ hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s);    
 bool conv_tap_stream_ok(const ConvParams &p, int variant);                         // the persistent form takes this launch
 bool conv_tap_fits(int variant, int W);
 bool conv_tap_is2d(int variant);
+bool conv_tap_image_aligned(int variant);   // a tile = one whole image of the padded-linear grid (tile stride (H+1)(W+1))
 bool conv_tap_f32_ok(int variant);            // float32 instantiation usable (tiles with room for the second accumulator)
 bool dma_cfg_f32_ok(int cfg);
 const char *dma_cfg_name(int cfg);

@@ -211,6 +211,7 @@ def test_dominant_kernel_register_allocation_is_guarded():
         "ILb0ELi2ELi4ELi8ELi4ELi26ELi2ELi1ELb0ELb1ELb0EE": (0, 2),      # 256 x 256
         "ILb0ELi4ELi2ELi4ELi7ELi17ELi2ELi1ELb0ELb1ELb0EE": (0, 2),      # 256 x 224
         "ILb0ELi4ELi2ELi4ELi7ELi17ELi2ELi1ELb0ELb0ELb0EE": (0, 2),
+        "ILb0ELi2ELi4ELi4ELi6ELi27ELi2ELi1ELb0ELb1ELb0EE": (0, 2),      # 128 x 384, image-aligned (19 x 19 layers)
         "ILb0ELi2ELi4ELi4ELi3ELi26ELi4ELi1ELb0ELb1ELb0EE": (0, 4),      # 128 x 192
         "ILb0ELi2ELi4ELi4ELi2ELi28ELi4ELi1ELb0ELb1ELb0EE": (0, 4),      # 128 x 128
         "ILb0ELi2ELi4ELi4ELi2ELi28ELi4ELi1ELb1ELb0ELb0EE": (0, 4),      # 128 x 128 split-K
