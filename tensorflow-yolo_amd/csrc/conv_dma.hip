@@ -269,8 +269,9 @@ static const DmaCfg kCfgs[] = {
     {128, 128, 3, 1.00f, "128x128,tap9,2d,x3", 4},     // 16: conv_tap.hip variant 7: 8 x 16 2-D tile, three workgroups per CU
     {32, 256, 2, 1.00f, "32x256,tap9,2d,x2", 4},       // 17: conv_tap.hip variant 8: 32 couts x (16 x 16)
     {128, 384, 1, 1.00f, "128x384,tap9,img", 4},       // 18: conv_tap.hip variant 9: one whole image (19 x 19) per tile
+    {128, 192, 1, 1.00f, "128x192,K64,S4", 8},         // 19: conv_dma again: the whole LDS as a four-stage ring (120 KiB in flight), for one-round 1x1 layers on small maps
 };
-static const int kNumCfgs = 19;
+static const int kNumCfgs = 20;
 static const int kFirstTapCfg = 8, kLastTapCfg = 13;
 static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || (cfg >= 15 && cfg <= 18); }
 static inline int tap_variant(int cfg) { return cfg >= 15 ? cfg - 9 : cfg - kFirstTapCfg; }     // conv_tap.hip variant of a tap cfg
@@ -320,6 +321,7 @@ static const TileCost kCost[] = {
     {0.0f, 0.0f, 0.0f, 0.0f},           // 16: 128x128 2-D tap reuse, three per CU (chosen by rule)
     {0.0f, 0.0f, 0.0f, 0.0f},           // 17: 32x256 2-D tap reuse (chosen by rule)
     {0.90f, 0.90f, 0.90f, 18.0f},       // 18: 128x384 image-aligned tap reuse (6/7 of the 256x224 tile's loop)
+    {0.60f, 0.60f, 0.60f, 12.0f},       // 19: 128x192 K64 S4
 };
 
 int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W, bool tap_only) {
@@ -366,6 +368,7 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
         // (with <= 128 workgroups the 4-wave kernel's split-K wins: 25 vs 49 us at batch 1)
         const long long wg128 = (long long)((M + 127) / 128) * ((cout + 127) / 128);
         if (c == 14 && taps != 1 && !(stride == 2 && wg128 > 128 && wg128 <= 256)) continue;
+        if (c == 19 && taps != 1) continue;     // (measured on 1x1 layers only)
         if (c == 7 || c == 13 || c == 16 || c == 17 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
         const DmaCfg &k = kCfgs[c];
         // tap-reuse tiles walk the padded position grid: (H+1)(W+1) positions per image (square maps assumed here)
@@ -411,7 +414,8 @@ const char *dma_cfg_name(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg
     X(5, 4, 2, 4, 4, 3, 4, 4) \
     X(6, 2, 4, 4, 4, 3, 4, 4) \
     X(7, 1, 8, 4, 4, 2, 4, 4) \
-    X(14, 2, 4, 4, 2, 3, 4, 6)
+    X(14, 2, 4, 4, 2, 3, 4, 6) \
+    X(19, 2, 4, 4, 3, 4, 8, 2)
 
 static hipError_t launch_dma_tile(const ConvParams &p, int cfg, hipStream_t s) {
     const dim3 grid((unsigned)p.n_blocks), block(512);

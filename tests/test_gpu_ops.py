@@ -393,7 +393,7 @@ def test_random_layer_shapes_through_the_default_rules(dtype):
         check_graph(g, x, dtype, seed=40 + case, read=tuple(read))
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 14])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 14, 19])
 def test_every_dma_tile_config(tile):
     """each LDS-DMA tile shape of conv_dma.hip, forced through yolo_net_options.force_tile (a tile
     that is not valid for a layer falls back to the heuristic), on a graph with 3x3/1, 3x3/2, 1x1, residual,
