@@ -264,7 +264,8 @@ bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile) {
     if (k.outmode == OUT_POOL2 && tile != 12 && tile != 13 && tile != 17) return false;      // the fused max-pool lives in the 16 x 16 2-D tap tiles
     if (tile == 0) return true;
     if (net->opt.dtype == YOLO_DTYPE_F32 && !dma_cfg_f32_ok(tile)) return false;
-    if (tile == 18 && k.in.H != k.in.W) return false;     // the image-aligned tap tile: square maps (the rules price tiles by W alone)
+    if ((tile == 18 || tile == 21) && k.in.H != k.in.W) return false;     // the image-aligned tap tiles: square maps (the rules price tiles by W alone)
+    if ((tile == 20 || tile == 21) && ((k.in.H & 1) || net->opt.dtype != YOLO_DTYPE_F16)) return false;      // stride 2 over parity planes: even maps, fp16
     return dma_eligible(net, k) && dma_cfg_valid(tile, k.cout, k.cpt, true, k.ksize, k.stride, k.in.W);
 }
 
@@ -323,6 +324,7 @@ ConvPick pick_conv(const yolo_net *net, const Kernel &k, const ConvParams &p, in
     else if (tile < 0) {
         tile = choose_dma_cfg(p.M, k.cout, k.cpt, p.taps, k.has_res, true, k.stride, k.in.W, net->opt.dtype == YOLO_DTYPE_F32);
         if (tile == 18 && !conv_tile_valid(net, k, 18)) tile = conv_tile_valid(net, k, 15) ? 15 : 8;
+        if ((tile == 20 || tile == 21) && !conv_tile_valid(net, k, tile)) tile = conv_tile_valid(net, k, 20) ? 20 : conv_tile_valid(net, k, 5) ? 5 : 0;
     }
     int ku = 0;
     int ks = choose_ksplit(k, p, tile, slab_bytes, ku);

@@ -270,11 +270,13 @@ static const DmaCfg kCfgs[] = {
     {32, 256, 2, 1.00f, "32x256,tap9,2d,x2", 4},       // 17: conv_tap.hip variant 8: 32 couts x (16 x 16)
     {128, 384, 1, 1.00f, "128x384,tap9,img", 4},       // 18: conv_tap.hip variant 9: one whole image (19 x 19) per tile
     {128, 192, 1, 1.00f, "128x192,K64,S4", 8},         // 19: conv_dma again: the whole LDS as a four-stage ring (120 KiB in flight), for one-round 1x1 layers on small maps
+    {128, 256, 2, 1.00f, "128x256,tap9,s2,x2", 4},     // 20: conv_tap.hip variant 10: 3x3 / stride 2 with tap reuse over the input's parity planes
+    {128, 384, 1, 1.00f, "128x384,tap9,s2,img", 4},    // 21: conv_tap.hip variant 11: ... one whole (19 x 19) output image per tile
 };
-static const int kNumCfgs = 20;
+static const int kNumCfgs = 22;
 static const int kFirstTapCfg = 8, kLastTapCfg = 13;
-static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || (cfg >= 15 && cfg <= 18); }
-static inline int tap_variant(int cfg) { return cfg >= 15 ? cfg - 9 : cfg - kFirstTapCfg; }     // conv_tap.hip variant of a tap cfg
+static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || (cfg >= 15 && cfg <= 18) || cfg == 20 || cfg == 21; }
+static inline int tap_variant(int cfg) { return cfg >= 20 ? cfg - 10 : cfg >= 15 ? cfg - 9 : cfg - kFirstTapCfg; }     // conv_tap.hip variant of a tap cfg
 bool dma_cfg_is_tap(int cfg) { return is_tap_cfg(cfg); }
 bool dma_cfg_f32_ok(int cfg) { return is_tap_cfg(cfg) && conv_tap_f32_ok(tap_variant(cfg)); }
 
@@ -285,7 +287,7 @@ bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok, int ksize, int
     if (cfg < 0 || cfg >= kNumCfgs) return false;
     const DmaCfg &k = kCfgs[cfg];
     if (cin_chunks % k.bkc) return false;
-    if (is_tap_cfg(cfg) && (ksize != 3 || stride != 1 || !conv_tap_fits(tap_variant(cfg), W))) return false;
+    if (is_tap_cfg(cfg) && (ksize != 3 || stride != (conv_tap_stride2(tap_variant(cfg)) ? 2 : 1) || !conv_tap_fits(tap_variant(cfg), W))) return false;
     if (k.na == 32) return cout <= 32 && cout > 16;
     if (k.na == 64) return cout <= 64 && (!is_tap_cfg(cfg) || cout > 32);
     return k.na <= (cout + 127) / 128 * 128 && cout > 64;
@@ -322,6 +324,8 @@ static const TileCost kCost[] = {
     {0.0f, 0.0f, 0.0f, 0.0f},           // 17: 32x256 2-D tap reuse (chosen by rule)
     {0.90f, 0.90f, 0.90f, 18.0f},       // 18: 128x384 image-aligned tap reuse (6/7 of the 256x224 tile's loop)
     {0.60f, 0.60f, 0.60f, 12.0f},       // 19: 128x192 K64 S4
+    {1.20f, 1.45f, 0.76f, 7.9f},        // 20: 128x256 stride-2 tap reuse, two per CU (as tile 8)
+    {0.90f, 0.90f, 0.90f, 18.0f},       // 21: 128x384 image-aligned stride-2 tap reuse (as tile 18)
 };
 
 int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W, bool tap_only) {
@@ -373,12 +377,16 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
         const DmaCfg &k = kCfgs[c];
         // tap-reuse tiles walk the padded position grid: (H+1)(W+1) positions per image (square maps assumed here)
         long long Meff = M;
-        if (is_tap_cfg(c)) {
+        const int Wq = is_tap_cfg(c) && conv_tap_stride2(tap_variant(c)) ? W / 2 : W;      // width of the map the tap tiles walk
+        if (is_tap_cfg(c) && conv_tap_stride2(tap_variant(c))) {
+            if (cin_chunks <= 8) continue;      // (Cin <= 64, two slices: the LDS-DMA tile that also computes the 1x1 behind it is the better launch)
+            Meff = (long long)M * (Wq + 1) * (Wq + 1) / ((long long)Wq * Wq);
+        } else if (is_tap_cfg(c)) {
             if (conv_tap_is2d(tap_variant(c))) { const long long th = k.nb / 16, tx = (W + 15) / 16, ty = (W + th - 1) / th; Meff = (long long)M * tx * ty * k.nb / ((long long)W * W); }
             else Meff = (long long)M * (W + 1) * (W + 1) / ((long long)W * W);
         }
         long long blocks = (Meff + k.nb - 1) / k.nb * ((cout + k.na - 1) / k.na);
-        if (is_tap_cfg(c) && conv_tap_image_aligned(tap_variant(c))) blocks = (long long)(M / (W * W)) * ((cout + k.na - 1) / k.na);    // a tile per image
+        if (is_tap_cfg(c) && conv_tap_image_aligned(tap_variant(c))) blocks = (long long)(M / (Wq * Wq)) * ((cout + k.na - 1) / k.na);    // a tile per image
         const long long slots = 256LL * k.slots_per_cu;     // resident workgroups on the chip
         // one workgroup per CU: whole rounds; two per CU: the dispatcher back-fills, the tail costs ~half a round
         double rounds, a;
@@ -484,8 +492,8 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
             p.qHW = p.qW * ((p.H + th - 1) / th);
             mq = (long long)(p.M / p.HoWo) * p.qHW * k.nb;
         } else {
-            p.qW = p.W + 1;
-            p.qHW = (p.H + 1) * (p.W + 1);
+            p.qW = p.Wo + 1;          // (stride 1: Ho = H, Wo = W; the stride-2 tiles walk the OUTPUT map)
+            p.qHW = (p.Ho + 1) * (p.Wo + 1);
             mq = (long long)(p.M / p.HoWo) * p.qHW;
         }
         const bool img = conv_tap_image_aligned(tap_variant(cfg));
@@ -514,7 +522,7 @@ std::string dma_cfg_symbol_for(int cfg, bool f32, const ConvParams &p) {
     if (p.fuse2) return cfg == 6 ? "void yolo::conv_igemm_dma_kernel<2, 4, 4, 4, 3, 4, 4, true>(yolo::ConvParams)"
                                  : "void yolo::conv3x3_tap_kernel<false, 2, 4, 4, 4, 27, 4, 2, false, true, true>(yolo::ConvParams)";
     if (is_tap_cfg(cfg) && conv_tap_stream_ok(p, tap_variant(cfg))) return conv_tap_stream_symbol(tap_variant(cfg));
-    std::string sym = dma_cfg_symbol(cfg, f32, is_tap_cfg(cfg) && !f32 && conv_fast_epilogue_ok(p));
+    std::string sym = dma_cfg_symbol(cfg, f32, is_tap_cfg(cfg) && !f32 && conv_fast_epilogue_ok(p) && cfg != 20);
     if (is_tap_cfg(cfg) && p.outmode == OUT_POOL2) {        // the fused-pool instantiation: template argument MODE 3 instead of 2
         const size_t at = sym.rfind(", 2, false, false, false>(");
         if (at != std::string::npos) sym.replace(at, 26, ", 3, false, false, false>(");

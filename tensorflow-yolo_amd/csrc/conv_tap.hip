@@ -74,7 +74,8 @@ constexpr int kTapStreamBiasFloats = 512;      // stream kernel: couts whose bia
 template <bool F32, int WM, int WN, int TM, int TP, int PRG, int OCC, int MODE, bool SPLITK, bool FAST = false, bool FUSE2 = false>
 __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams p) {
     typedef typename std::conditional<F32, float, _Float16>::type T;
-    constexpr bool TWO_D = MODE >= 2;       // MODE 3: the 2-D tiles of MODE 2 with the max-pool behind the conv taken in the epilogue
+    constexpr bool TWO_D = MODE == 2 || MODE == 3;       // MODE 3: the 2-D tiles of MODE 2 with the max-pool behind the conv taken in the epilogue
+    constexpr bool S2 = MODE == 4;          // 3x3 / stride 2 over the four parity planes of the input (see run_slice_s2 below)
     constexpr int PADQ = TWO_D ? 2 : 1;
     constexpr int NW = 8;
     constexpr int S = 3;                    // weight ring slots (9 taps per slice: slot = tap % 3)
@@ -99,6 +100,8 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     if constexpr (SPLITK && !(WM == 2 && WN == 4 && TM == 4 && (TP == 2 || (TP == 4 && !F32)) && MODE == 1)) return;    // split-K: the 128 x 128 tile; 128 x 256 (fp16) for the in-launch pair
     if constexpr (MODE == 3 && (TP % 2 != 0 || SPLITK)) return;      // split-K: the 128 x 128 tile only
     static_assert(!FAST || (!F32 && !SPLITK && MODE != 3), "the lean epilogue: fp16, whole K, plain output");
+    static_assert(!S2 || (!FUSE2 && JA_TOT % NW == 0), "stride 2: every wave carries weights");
+    if constexpr (S2 && (F32 || SPLITK)) return;            // never launched (launch_conv_tap refuses): fp16, whole K only
     static_assert(!FUSE2 || (FAST && WM == 2 && WN == 4 && TM == 4 && TP == 4), "back-to-back 1x1: the 128 x 256 tiles");
     constexpr int LDS_BYTES = FUSE2 && kFuse2LdsBytes > S * A_BYTES + 2 * P_BYTES ? kFuse2LdsBytes : S * A_BYTES + 2 * P_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
@@ -166,7 +169,8 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
             const int r = qq - n * p.qHW;
             y = (int)fdiv((uint32_t)r, p.dqW);
             x = r - y * p.qW;
-            ok = ok && x < p.W && y < p.H;
+            if (S2) { ok = ok && x < p.Wo && y < p.Ho; y *= 2; x *= 2; }     // plane (0, 0) of the input: pixel (2 y', 2 x')
+            else ok = ok && x < p.W && y < p.H;
         }
         const long long e = (long long)n * p.in_img_stride + ((long long)y * p.W + x) * p.in_ld + p.in_coff;
         b_off[j] = ok ? (uint32_t)(e * (long long)sizeof(T)) + csw_p : YOLO_INVALID_OFF;
@@ -176,8 +180,8 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     const int c_begin = SPLITK ? (int)blockIdx.y * p.kunits : 0;
     const int C = SPLITK ? ((c_begin + p.kunits < (p.cin_chunks >> 2)) ? c_begin + p.kunits : (p.cin_chunks >> 2)) : (p.cin_chunks >> 2);
     const int KT = 9 * C;
-    auto issue_patch = [&](int c, int buf) {
-        const uint32_t koff = (uint32_t)c * ROWB;
+    auto issue_patch = [&](int c, int buf, uint32_t plane_off = 0u) {
+        const uint32_t koff = (uint32_t)c * ROWB + plane_off;
 #pragma unroll
         for (int j = 0; j < JP; ++j)
             if (j + 1 < JP || jp_full) tap_dma16(rs_in, smemP + buf * P_BYTES + (j * NW + wave) * 1024, b_off[j], koff);
@@ -244,9 +248,57 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
 #ifdef YOLO_EXPERIMENT
     const unsigned long long t_setup = p.trace ? wall_clock64() : 0ull;
 #endif
-    issue_patch(c_begin, 0);
-    issue_weights(0, c_begin, 0);
-    issue_weights(1, c_begin, 1);
+    // STRIDE 2 (MODE 4).  Output position (y, x) reads input pixel (2y + kh - 1, 2x + kw - 1): row 2y - 1 / 2y / 2y + 1 lies in the
+    // row-parity plane 1 / 0 / 1 at plane row y - 1 / y / y (columns alike), so over the four parity planes P[py][px](y', x') =
+    // in(2y' + py, 2x' + px) -- each of the OUTPUT's size -- the conv is nine (plane, shift) pairs with shifts dy, dx in {-1, 0}:
+    // plane (1,1) four taps, (1,0) and (0,1) two each, (0,0) one.  The positions walk the padded-linear grid of the OUTPUT map
+    // (qW = Wo + 1), a patch is NB + Wo + 2 positions of ONE plane (row R <-> position q0 - (Wo + 2) + R, tap shift
+    // (dy + 1) qW + (dx + 1)), gathered by the same per-lane LDS-DMA offsets for every plane (a pad position is a pad position in
+    // all four; the plane's pixel offset (py W + px) in_ld rides in the DMA's scalar offset).  Per 32-channel slice the tap order is
+    // A A D A A B B C C (A = plane (1,1), D = (0,0), B = (1,0), C = (0,1)) over TWO patch buffers X, Y that swap roles from slice
+    // to slice: A in X; D -> Y requested at step 0 (Y held the last slice's C), B -> Y at step 3 (after D's only tap), C -> X at
+    // step 5 (after A's last), the next slice's A -> Y at step 7 (after B's last): every patch is requested two taps before its
+    // first use, like the weights.  4 x 21 KiB of patch + 72 KiB of weights per slice and 128 x 256 tile against 9 x 16 + 72 KiB
+    // for the per-tap gather of conv_dma.hip -- and two workgroups per CU.
+    const uint32_t pl01 = S2 ? (uint32_t)p.in_ld * 2u : 0u, pl10 = S2 ? (uint32_t)(p.W * p.in_ld) * 2u : 0u;
+    if constexpr (S2) {
+        issue_patch(c_begin, 0, pl10 + pl01);
+        issue_weights(0, c_begin, 0);
+        issue_weights(2, c_begin, 1);
+    } else {
+        issue_patch(c_begin, 0);
+        issue_weights(0, c_begin, 0);
+        issue_weights(1, c_begin, 1);
+    }
+    auto run_slice_s2 = [&](int c, auto bufc) {
+        constexpr int X = decltype(bufc)::value, Y = X ^ 1;
+        constexpr int kTapOf[9] = {0, 2, 4, 6, 8, 1, 7, 3, 5};          // kh * 3 + kw of step s
+        constexpr int kBufOf[9] = {X, X, Y, X, X, Y, Y, X, X};
+        constexpr int kShOf[9] = {0, 1, 3, 2, 3, 1, 3, 2, 3};           // shift code: bit 1 = + qW (dy = 0), bit 0 = + 1 (dx = 0)
+        const bool more = c + 1 < C;
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            // in flight behind what this step needs: the weights of step s + 1 and the patch requested at step s - 1 (if any)
+            const bool last = !more && s == 8;
+            const bool patch_prev = s == 1 || s == 4 || s == 6 || (s == 8 && more);
+            if (last) tap_wait_vm<0>();
+            else if (!patch_prev) tap_wait_vm<JA>();
+            else if (jp_full) tap_wait_vm<JA + JP>();
+            else tap_wait_vm<JA + JP - 1>();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            {   // weights two steps ahead
+                const int s2 = s + 2 < 9 ? s + 2 : s + 2 - 9;
+                const int c2 = s + 2 < 9 ? c : c + 1;
+                if (c2 < C) issue_weights(kTapOf[s2], c2, (s + 2) % S);
+            }
+            if (s == 0) issue_patch(c, Y, 0u);
+            if (s == 3) issue_patch(c, Y, pl10);
+            if (s == 5) issue_patch(c, X, pl01);
+            if (s == 7 && more) issue_patch(c + 1, Y, pl10 + pl01);
+            compute(s % S, kBufOf[s], ((kShOf[s] & 2) ? p.qW : 0) + (kShOf[s] & 1));
+        }
+    };
 
     // one 32-channel slice; the patch buffer index is a compile-time constant (LDS immediates, no address registers)
     auto run_slice = [&](int c, auto bufc) {
@@ -285,8 +337,13 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         }
     };
     for (int c = c_begin; c < C; c += 2) {
-        run_slice(c, std::integral_constant<int, 0>());
-        if (c + 1 < C) run_slice(c + 1, std::integral_constant<int, 1>());
+        if constexpr (S2) {
+            run_slice_s2(c, std::integral_constant<int, 0>());
+            if (c + 1 < C) run_slice_s2(c + 1, std::integral_constant<int, 1>());
+        } else {
+            run_slice(c, std::integral_constant<int, 0>());
+            if (c + 1 < C) run_slice(c + 1, std::integral_constant<int, 1>());
+        }
         if constexpr (F32) flush_acc<TM, TP>(acc, acc2);        // two 16-channel slices x 9 taps = 288 k per chain
     }
     if constexpr (F32) {
@@ -643,11 +700,13 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_stream_kernel(const Conv
 // 380), tile m starts at position m (H+1)(W+1) -- the shared pad row behind every image is never computed (6 % of the positions are
 // padding instead of 10.8 %) and 19 x 19 at batch 32 is 32 x 8 = 256 tiles: every CU busy, 14 % less work per CU than the 232 tiles
 // of variant 6
-static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224, 128, 256, 384};
-static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17, 12, 27, 27};
-static const int kTapVariants = 10;
-static const bool kTapF32[] = {false, false, false, true, false, true, false, false, true, false};      // float32 tiles: TP <= 2 (second-level accumulator)
-bool conv_tap_image_aligned(int variant) { return variant == 9; }
+// 10 = 128 x 256 and 11 = 128 x 384 image-aligned for 3x3 / STRIDE 2 (MODE 4: parity planes of the input, see the kernel): fp16 only
+static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224, 128, 256, 384, 256, 384};
+static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17, 12, 27, 27, 21, 26};
+static const int kTapVariants = 12;
+static const bool kTapF32[] = {false, false, false, true, false, true, false, false, true, false, false, false};      // float32 tiles: TP <= 2 (second-level accumulator)
+bool conv_tap_image_aligned(int variant) { return variant == 9 || variant == 11; }
+bool conv_tap_stride2(int variant) { return variant == 10 || variant == 11; }
 bool conv_tap_splitk_ok(int variant) { return variant == 3; }      // the 128 x 128 tile has the (two-pass) split-K instantiation
 bool conv_tap_pair_ok(int variant, bool f32) { return variant == 3 || (variant == 0 && !f32); }   // in-launch pair split: also the fp16 128 x 256 tile
 bool conv_tap_is2d(int variant) { return variant == 4 || variant == 5 || variant == 7 || variant == 8; }
@@ -655,8 +714,13 @@ bool conv_tap_f32_ok(int variant) { return variant >= 0 && variant < kTapVariant
 bool conv_tap_fits(int variant, int W) {
     if (variant < 0 || variant >= kTapVariants) return false;
     if (conv_tap_is2d(variant)) return true;
+    if (conv_tap_stride2(variant)) {        // W = the INPUT's width (even); the position grid is the output's
+        if (W & 1) return false;
+        W >>= 1;
+    }
     // (the image-aligned tile: square maps of 17 .. 19 -- a whole image per tile with at least 80 % of the positions real)
     if (conv_tap_image_aligned(variant) && (W * (W + 1) > kTapNB[variant] || W * (W + 1) * 5 < kTapNB[variant] * 4)) return false;
+    if (conv_tap_stride2(variant)) return kTapNB[variant] + W + 2 <= kTapPRG[variant] * 16;
     return kTapNB[variant] + 2 * W + 4 <= kTapPRG[variant] * 16;
 }
 
@@ -672,7 +736,9 @@ bool conv_tap_fits(int variant, int W) {
     X(6, 4, 2, 4, 7, 17, 2, 1) \
     X(7, 2, 4, 4, 2, 12, 6, 2) \
     X(8, 1, 8, 2, 2, 27, 4, 2) \
-    X(9, 2, 4, 4, 6, 27, 2, 1)
+    X(9, 2, 4, 4, 6, 27, 2, 1) \
+    X(10, 2, 4, 4, 4, 21, 4, 4) \
+    X(11, 2, 4, 4, 6, 26, 2, 4)
 
 const char *conv_tap_symbol(int variant, bool f32, bool fast) {
     switch (variant) {
@@ -726,11 +792,15 @@ static hipError_t launch_conv_tap_stream(const ConvParams &p0, int variant, hipS
 hipError_t launch_conv_tap(const ConvParams &p0, int variant, hipStream_t s) {
     ConvParams p = p0;
     static const bool no_fast_epi = getenv("YOLO_NO_FAST_EPI") != nullptr;        // A/B switch, read once (same results either way)
-    p.fast_epi = !no_fast_epi && conv_fast_epilogue_ok(p) ? 1 : 0;
-    if (p.ksize != 3 || p.stride != 1 || p.pad != 1 || p.Ho != p.H || p.Wo != p.W || (p.cin_chunks & 3) || !conv_tap_fits(variant, p.W) ||
-        (p.f32 && !conv_tap_f32_ok(variant)))
+    // (variant 10, the two-per-CU stride-2 tile: its lean instantiation spills 13 registers at the 128-register limit; the generic one does not)
+    p.fast_epi = !no_fast_epi && conv_fast_epilogue_ok(p) && variant != 10 ? 1 : 0;
+    const bool s2 = conv_tap_stride2(variant);
+    if (p.ksize != 3 || p.stride != (s2 ? 2 : 1) || p.pad != 1 || (p.cin_chunks & 3) || !conv_tap_fits(variant, p.W) || (p.f32 && !conv_tap_f32_ok(variant)))
         return hipErrorInvalidValue;
-    if (conv_tap_image_aligned(variant) ? (p.q_stride != p.qHW || p.H * (p.W + 1) > kTapNB[variant]) : (!conv_tap_is2d(variant) && p.q_stride != kTapNB[variant]))
+    if (s2 ? ((p.H & 1) || (p.W & 1) || p.Ho * 2 != p.H || p.Wo * 2 != p.W || p.f32 || p.ksplit > 1 || p.fuse2 || p.outmode == OUT_POOL2 || p.qW != p.Wo + 1)
+           : (p.Ho != p.H || p.Wo != p.W))
+        return hipErrorInvalidValue;
+    if (conv_tap_image_aligned(variant) ? (p.q_stride != p.qHW || p.Ho * (p.Wo + 1) > kTapNB[variant]) : (!conv_tap_is2d(variant) && p.q_stride != kTapNB[variant]))
         return hipErrorInvalidValue;
     if (p.outmode == OUT_POOL2 && ((variant != 4 && variant != 5 && variant != 8) || (p.H & 1) || (p.W & 1) || p.has_res || p.ksplit > 1 || !p.vec_out || p.Cout % 16))
         return hipErrorInvalidValue;        // the fused pool lives in the 2-D tiles' epilogue only (plan.cpp asks for it accordingly)

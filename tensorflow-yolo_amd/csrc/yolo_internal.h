@@ -275,6 +275,7 @@ hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s);    
 bool conv_tap_stream_ok(const ConvParams &p, int variant);                         // the persistent form takes this launch
 bool conv_tap_fits(int variant, int W);
 bool conv_tap_is2d(int variant);
+bool conv_tap_stride2(int variant);         // 3x3 / stride 2 over the input's parity planes (MODE 4)
 bool conv_tap_image_aligned(int variant);   // a tile = one whole image of the padded-linear grid (tile stride (H+1)(W+1))
 bool conv_tap_f32_ok(int variant);            // float32 instantiation usable (tiles with room for the second accumulator)
 bool dma_cfg_f32_ok(int cfg);

@@ -363,6 +363,28 @@ def test_tap_reuse_conv_shapes(shape, tile):
         assert "tap9" in names, names
 
 
+@pytest.mark.parametrize("shape", [(3, 38, 38, 256, 512), (2, 76, 76, 128, 256), (1, 152, 152, 128, 256), (2, 22, 150, 64, 128),
+                                   (5, 12, 20, 32, 128), (2, 36, 36, 192, 384), (1, 34, 34, 128, 320)])
+@pytest.mark.parametrize("tile", [20, 21])
+def test_stride2_tap_reuse_tiles(shape, tile):
+    """conv_tap.hip MODE 4: 3x3 / stride 2 as nine (parity plane, shift) taps over the padded-linear grid of the OUTPUT map
+    (net/layers.py:17-30: explicit pad 1 + VALID, stride 2): Darknet-53's stage transitions (38 -> 19, 76 -> 38, 152 -> 76), a wide
+    map (patch of 256 + 77 positions), six channel slices (the patch buffers swap roles per slice), Cout with a tail, one slice only; tiles that span image rows, images and the end of the batch.  Tile 21 (one whole output image per tile) is
+    valid for the 17 x 17 .. 19 x 19 outputs only; elsewhere the default tile runs."""
+    B, H, W, cin, cout = shape
+    g = new_graph(H, W, cin)
+    g.append(PL.conv2d_bn_act(g[-1].out, cout, 3, 2))                # 1: the stride-2 conv
+    g.append(PL.conv2d_bn_act(g[-1].out, 64, 1, 1))                  # 2
+    g.append(PL.conv2d_bn_act(g[-1].out, cout, 3, 1))                # 3
+    g.append(PL.shortcut(g[-1].out, g[1].out))                       # 4
+    g.append(PL.max_pool2d(g[-1].out, 2, stride=1))
+    x = synth.synthetic_input(B, H, W, cin, seed=31)
+    eng = check_graph(g, x, "fp16", seed=9, read=(1, 4), tile=tile)
+    names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
+    if tile == 20 or (H == W and 34 <= W <= 38):
+        assert ",s2," in names, names
+
+
 @pytest.mark.parametrize("dtype", ["fp16", "fp32"])
 def test_random_layer_shapes_through_the_default_rules(dtype):
     """Seeded random conv stacks through the built-in tile rules (no forced tile): map sizes around the rule boundaries (13/14, 96,
