@@ -387,6 +387,8 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
         }
         long long blocks = (Meff + k.nb - 1) / k.nb * ((cout + k.na - 1) / k.na);
         if (is_tap_cfg(c) && conv_tap_image_aligned(tap_variant(c))) blocks = (long long)(M / (Wq * Wq)) * ((cout + k.na - 1) / k.na);    // a tile per image
+        // (a stride-2 launch of a handful of tiles belongs to the 4-wave kernel, which splits K: 38 -> 19 at batch 1 25 us there, 58 us here)
+        if (is_tap_cfg(c) && conv_tap_stride2(tap_variant(c)) && blocks <= 128) continue;
         const long long slots = 256LL * k.slots_per_cu;     // resident workgroups on the chip
         // one workgroup per CU: whole rounds; two per CU: the dispatcher back-fills, the tail costs ~half a round
         double rounds, a;
