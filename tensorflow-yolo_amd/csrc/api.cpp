@@ -3,6 +3,7 @@
 #include <cstring>
 #include <new>
 
+#include <cmath>
 #include "yolo_internal.h"
 
 namespace yolo {
@@ -240,6 +241,7 @@ int make_conv_params(yolo_net *net, const Kernel &k, const Ptrs &P, int batch, C
         if (k.out.ld % width == 0 && base % width == 0 && rows * width == net->out_count && (size_t)batch * rows * 4 <= net->obj_bytes) {
             p.obj_out = reinterpret_cast<float *>(net->dev_ws + net->obj_off) + (size_t)P.img0 * rows;
             p.obj_width = width; p.obj_rows = (int)rows; p.obj_row0 = (int)(base / width); p.obj_na = k.out.ld / width;
+            p.obj_min = net->obj_min_logit;     // -inf outside yolo_net_detect: every row is written
         }
     }
     if (k.has_res) {
@@ -583,6 +585,23 @@ int run_forward_pass(yolo_net *net, const float *in_dev, int batch, float *out_d
 // ones, fork/join by events): images are independent, so the ragged tail + cold start of every kernel of one part overlaps
 // the bulk of the other parts' kernels instead of leaving CUs idle at each of the ~73 kernel boundaries.  Every part has
 // its own activation arena (plan.cpp: allocate).
+// every head conv of the plan fills the compact objectness array at this batch (what run_forward_impl finds out afterwards as obj_valid)
+bool all_heads_write_objectness(yolo_net *net, const float *in_dev, float *out_dev, int batch) {
+    if (!net->obj_bytes || net->head.n_classes <= 0) return false;
+    const int per = net->parts >= 2 && batch > part_batch(net) ? part_batch(net) : batch;
+    Ptrs P{net, in_dev, out_dev, 0, 0};
+    bool any = false;
+    for (const Kernel &k : net->kernels) {
+        if (k.kind != K_CONV || !k.head) continue;
+        ConvParams p;
+        if (make_conv_params(net, k, P, per, p) != 0 || !p.obj_out) return false;
+        // (the rows reach the compact array through the staged float32 epilogue of the LDS-DMA tiles or the 4-wave kernel, or through
+        // the split-K reduce kernel: all of them honour obj_out)
+        any = true;
+    }
+    return any;
+}
+
 int run_forward_impl(yolo_net *net, const float *in_dev, int batch, float *out_dev, hipStream_t s, hipEvent_t *ev);
 int run_forward(yolo_net *net, const float *in_dev, int batch, float *out_dev, hipStream_t s, hipEvent_t *ev = nullptr) {
     const int rc = run_forward_impl(net, in_dev, batch, out_dev, s, ev);
@@ -943,7 +962,16 @@ int yolo_net_detect(yolo_net *net, const float *in_dev, int batch, double thresh
     if (rc) return fail(YOLO_ERR_STATE, "yolo_net_detect: head geometry not set (" + err + "); call yolo_net_set_head");
     hipStream_t s = static_cast<hipStream_t>(stream);
     float *logits = reinterpret_cast<float *>(net->dev_ws + net->logits_off);
+    // The logits of a detect call never leave the workspace, and the decode kernel reads the objectness of every row from the compact
+    // array the head convs fill and the rest of a row only where sigmoid(objectness) reaches the threshold (p = sigmoid(obj) in v3,
+    // <= sigmoid(obj) in v2): rows 0.01 below the threshold's logit are not written (conv_common.h: conv_epilogue_f32_staged).  Only
+    // when EVERY head conv of this plan writes the compact array -- else the decode would look for objectness in rows never written.
+    static const bool dense = getenv("YOLO_DENSE_LOGITS") != nullptr;       // A/B switch (same boxes either way)
+    net->obj_min_logit = -INFINITY;
+    if (!dense && threshold > 0.0 && threshold < 1.0 && all_heads_write_objectness(net, in_dev, logits, batch))
+        net->obj_min_logit = (float)(std::log(threshold / (1.0 - threshold)) - 0.01);
     rc = run_forward(net, in_dev, batch, logits, s);
+    net->obj_min_logit = -INFINITY;
     if (rc) return rc;
     return run_decode_nms(net->head, logits, batch, threshold, iou_threshold, nms_mode, net->opt.cand_capacity,
                           net->opt.max_boxes, net->dev_ws + net->cand_off, reinterpret_cast<int *>(net->dev_ws + net->count_off),

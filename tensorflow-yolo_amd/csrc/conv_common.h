@@ -507,9 +507,18 @@ __device__ __forceinline__ void conv_store_partial(const ConvParams &p, float4v 
 // pixel's run of 64 consecutive floats (256 contiguous bytes) with one instruction.  OUT_NORMAL, no residual.
 constexpr int kStagePitch(int TM) { return 16 * TM + 4; }       // floats per pixel row of the slab (4 CH + pad)
 
+// SPARSE ROWS (detect only: ConvParams.obj_min > -inf; `flags` = workgroup-shared LDS, [pixels of the tile][8 anchors], pix0 = the
+// wave's first pixel in it): a (cell, anchor) row of 5 + classes logits whose objectness logit is below obj_min can never pass the
+// score threshold (v3: p = sigmoid(obj); v2: p = sigmoid(obj) * softmax <= sigmoid(obj); obj_min = logit(threshold) - 0.01), and
+// the decode kernel reads the rows of passing candidates only (detect.hip), so such rows are not written at all: the compact
+// objectness array stays complete, the 76 x 76 head of YOLOv3-608 stops writing 188 MB of float32 per batch of 32.  The lanes that
+// hold an objectness channel publish the verdict per (pixel, anchor); after a workgroup barrier every wave skips the stores of the
+// columns of a failed anchor.  yolo_net_forward (dense logits for the caller) never sets obj_min.
+constexpr int kStageFlagAnchors = 8;
+
 template <int TM, int TP, int PADQ = 0, bool BIAS_IN_ACC = false>
 __device__ __forceinline__ void conv_epilogue_f32_staged(const ConvParams &p, float4v (&acc)[TM][TP], int cbase_wave, int m_wave,
-                                                         int lane, float *slab) {
+                                                         int lane, float *slab, float *flags = nullptr, int pix0 = 0) {
     constexpr int CH = 4 * TM;
     constexpr int PITCH = kStagePitch(TM);
     const int fr = lane & 15, fq = lane >> 4;
@@ -542,12 +551,27 @@ __device__ __forceinline__ void conv_epilogue_f32_staged(const ConvParams &p, fl
     // objectness logits (channel a * (5+C) + 4 of anchor a) also go to a compact [B][rows] array for the decode kernel,
     // which otherwise touches one 64-byte sector per row to read 4 bytes of it
     constexpr int NH = (4 * CH + 63) / 64;
-    int obj_a[NH];
+    int obj_a[NH], col_a[NH];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         const int cg = cbase_wave + lane + 64 * h;
         const int a = p.obj_out ? cg / p.obj_width : 0;
         obj_a[h] = (p.obj_out && lane + 64 * h < 4 * CH && cg < p.Cout && cg - a * p.obj_width == 4) ? a : -1;
+        col_a[h] = a < kStageFlagAnchors ? a : kStageFlagAnchors - 1;
+    }
+    const bool sparse = flags != nullptr && p.obj_out != nullptr && p.obj_min > -3.0e38f && p.obj_na <= kStageFlagAnchors;    // kernel-uniform
+    if (sparse) {
+        int r = cbase % p.obj_width, a = cbase / p.obj_width;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            if (r == 4 && cbase + i < p.Cout) {
+#pragma unroll
+                for (int b = 0; b < TP; ++b)
+                    flags[(pix0 + b * 16 + fr) * kStageFlagAnchors + a] = acc[i >> 2][b][i & 3] >= p.obj_min ? 1.f : 0.f;
+            }
+            if (++r == p.obj_width) { r = 0; ++a; }
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
@@ -569,7 +593,7 @@ __device__ __forceinline__ void conv_epilogue_f32_staged(const ConvParams &p, fl
                 const int c = lane + 64 * h;
                 if (c < 4 * CH && cbase_wave + c < p.Cout) {
                     const float v = slab[pp * PITCH + c];
-                    op[po + cbase_wave + c] = v;
+                    if (!sparse || flags[(pix0 + b * 16 + pp) * kStageFlagAnchors + col_a[h]] != 0.f) op[po + cbase_wave + c] = v;
                     if (obj_a[h] >= 0) p.obj_out[orow_pp + obj_a[h]] = v;
                 }
             }

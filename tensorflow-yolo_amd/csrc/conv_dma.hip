@@ -223,10 +223,11 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
         conv_epilogue_fused_1x1<0, false>(p, acc, m0, wm, wn, wave, lane, smem);      // (the stride-2 conv into a stage: no residual)
     } else
     if (p.out_f32 && !p.vec_out && p.outmode == OUT_NORMAL && !p.has_res) {      // head conv: coalesced float32 rows via LDS
-        static_assert(8 * 16 * kStagePitch(TM) * 4 <= S * TILE_BYTES, "staging slabs must fit in the ring");
+        static_assert(8 * 16 * kStagePitch(TM) * 4 + NB * kStageFlagAnchors * 4 <= S * TILE_BYTES, "staging slabs + row flags must fit in the ring");
         __syncthreads();            // every wave is done reading the ring
         conv_epilogue_f32_staged<TM, TP, 0, true>(p, acc, n0 + wm * (TM * 16), m0 + wn * (TP * 16), lane,
-                                         reinterpret_cast<float *>(smem) + wave * 16 * kStagePitch(TM));
+                                         reinterpret_cast<float *>(smem) + wave * 16 * kStagePitch(TM),
+                                         reinterpret_cast<float *>(smem) + 8 * 16 * kStagePitch(TM), wn * (TP * 16));
     } else {
         conv_epilogue<T, TM, TP, 0, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, m0 + wn * (TP * 16), fr);
     }

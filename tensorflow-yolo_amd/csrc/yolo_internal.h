@@ -130,6 +130,7 @@ struct ConvParams {
     int t2_shift;              // conv_tap.hip MODE 2: log2 of the positions per 2-D tile (8: 16 x 16, 7: 8 x 16)
     float *obj_out;            // head convs (staged float32 epilogue): compact objectness logits [B][obj_rows] or null
     int obj_width, obj_rows, obj_row0, obj_na;     // 5 + classes; rows per image; first row of this scale; anchors per cell
+    float obj_min;             // head convs inside yolo_net_detect: rows whose objectness logit is below this are not written (conv_common.h); -inf: all rows
     unsigned long long *trace; // conv_tap.hip: per-block phase timestamps (YOLO_CONV_TRACE experiment) or null
     FastDiv dHoWo, dWo, dqHW, dqW, dtiles_n, dtpt;   // set by the launchers (conv_set_divisors); dtpt: K stages per tap
 };
@@ -355,6 +356,7 @@ struct yolo_net {
     size_t splitk_off = 0, splitk_bytes = 0;   // float32 partial-sum slabs of the split-K convs (small feature maps at small batch)
     size_t obj_off = 0, obj_bytes = 0;     // compact objectness logits [max_batch][rows] written by the head convs for the decode
     bool obj_valid = false;                // ... and whether the last forward filled all of it
+    float obj_min_logit = -__builtin_inff();      // inside yolo_net_detect: objectness logit below which a row can never be a candidate (ConvParams.obj_min)
     std::vector<hipStream_t> side;         // multi-stream forward (YOLO_STREAMS=N): internal streams + fork/join events
     hipEvent_t e_fork = nullptr;
     std::vector<hipEvent_t> e_join;

@@ -370,7 +370,7 @@ def test_stride2_tap_reuse_tiles(shape, tile):
     """conv_tap.hip MODE 4: 3x3 / stride 2 as nine (parity plane, shift) taps over the padded-linear grid of the OUTPUT map
     (net/layers.py:17-30: explicit pad 1 + VALID, stride 2): Darknet-53's stage transitions (38 -> 19, 76 -> 38, 152 -> 76), a wide
     map (patch of 256 + 77 positions), six channel slices (the patch buffers swap roles per slice), Cout with a tail, one slice only; tiles that span image rows, images and the end of the batch.  Tile 21 (one whole output image per tile) is
-    valid for the 17 x 17 .. 19 x 19 outputs only; elsewhere the default tile runs."""
+    valid for 18 x 18 and 19 x 19 outputs only; elsewhere the default tile runs."""
     B, H, W, cin, cout = shape
     g = new_graph(H, W, cin)
     g.append(PL.conv2d_bn_act(g[-1].out, cout, 3, 2))                # 1: the stride-2 conv
@@ -381,7 +381,7 @@ def test_stride2_tap_reuse_tiles(shape, tile):
     x = synth.synthetic_input(B, H, W, cin, seed=31)
     eng = check_graph(g, x, "fp16", seed=9, read=(1, 4), tile=tile)
     names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
-    if tile == 20 or (H == W and 34 <= W <= 38):
+    if (tile == 20 and B * (H // 2) * (W // 2) >= 1024) or (H == W and 36 <= W <= 38):     # (tile 21: outputs of 18 x 18 and 19 x 19)
         assert ",s2," in names, names
 
 
