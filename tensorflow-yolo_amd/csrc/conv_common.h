@@ -559,15 +559,21 @@ __device__ __forceinline__ void conv_epilogue_f32_staged(const ConvParams &p, fl
         obj_a[h] = (p.obj_out && lane + 64 * h < 4 * CH && cg < p.Cout && cg - a * p.obj_width == 4) ? a : -1;
         col_a[h] = a < kStageFlagAnchors ? a : kStageFlagAnchors - 1;
     }
-    const bool sparse = flags != nullptr && p.obj_out != nullptr && p.obj_min > -3.0e38f && p.obj_na <= kStageFlagAnchors;    // kernel-uniform
+    const bool sparse = flags != nullptr && p.obj_out != nullptr && p.obj_min > -3.0e38f && p.obj_na <= kStageFlagAnchors &&
+                        p.obj_width > CH;      // kernel-uniform; (5 + classes > CH: a lane's CH couts hold at most ONE objectness channel)
+    float objv[TP];             // the objectness logits this lane holds (pixel fr of every fragment), anchor obj_an; -1: none
+    int obj_an = -1;
     if (sparse) {
         int r = cbase % p.obj_width, a = cbase / p.obj_width;
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             if (r == 4 && cbase + i < p.Cout) {
+                obj_an = a;
 #pragma unroll
-                for (int b = 0; b < TP; ++b)
-                    flags[(pix0 + b * 16 + fr) * kStageFlagAnchors + a] = acc[i >> 2][b][i & 3] >= p.obj_min ? 1.f : 0.f;
+                for (int b = 0; b < TP; ++b) {
+                    objv[b] = acc[i >> 2][b][i & 3];
+                    flags[(pix0 + b * 16 + fr) * kStageFlagAnchors + a] = objv[b] >= p.obj_min ? 1.f : 0.f;
+                }
             }
             if (++r == p.obj_width) { r = 0; ++a; }
         }
@@ -580,6 +586,17 @@ __device__ __forceinline__ void conv_epilogue_f32_staged(const ConvParams &p, fl
         const long long off = (long long)n * p.out_img_stride + (long long)rem * p.out_ld;
         const int off_lo = (int)(off & 0xffffffffLL), off_hi = (int)(off >> 32), oki = ok ? 1 : 0;
         const int orow = n * p.obj_rows + p.obj_row0 + rem * p.obj_na;
+        if (sparse) {
+            // no anchor of these 16 pixels can be a candidate (the usual case): nothing of the fragment goes to the logits, its
+            // objectness logits go to the compact array straight from the lanes that hold them -- no slab, no store loop
+            bool any = false;
+            if (lane < 16)
+                for (int a = 0; a < p.obj_na; ++a) any = any || flags[(pix0 + b * 16 + lane) * kStageFlagAnchors + a] != 0.f;
+            if (!__builtin_amdgcn_ballot_w64(any)) {
+                if (ok && obj_an >= 0) p.obj_out[orow + obj_an] = objv[b];
+                continue;
+            }
+        }
 #pragma unroll
         for (int a = 0; a < TM; ++a) *reinterpret_cast<float4v *>(slab + fr * PITCH + fq * CH + 4 * a) = acc[a][b];
         __builtin_amdgcn_wave_barrier();        // LDS executes a wave's instructions in order: the reads below see these writes
