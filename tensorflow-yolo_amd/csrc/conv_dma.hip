@@ -54,7 +54,11 @@ __device__ __forceinline__ int lds_swz(int r) {
 // other's MFMA loop; with one lock-stepped workgroup per CU that traffic was 44 % of the layer time).
 // FUSE2: the 1x1 conv behind this one computed by the same workgroups (conv_common.h: conv_epilogue_fused_1x1); the 128 x 256 K32
 // tile only (all 128 couts of 256 pixels in one workgroup).
-template <int WM, int WN, int TM, int TP, int S, int BKC, int OCC, bool FUSE2 = false>
+// EPI: which epilogue this instantiation carries -- 0 the generic one (any output map / view), 1 the lean one of conv_common.h
+// (conv_epilogue_fast: plain fp16 output maps), 2 the head convs' float32 rows through LDS slabs (conv_epilogue_f32_staged).
+// Instantiations of their own, like in conv_tap.hip: with the three behind run-time branches in one kernel seven of the ten tiles
+// spilled 12-176 registers (the staged epilogue's row flags alone cost the generic path its last registers).
+template <int WM, int WN, int TM, int TP, int S, int BKC, int OCC, bool FUSE2 = false, int EPI = 0>
 __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvParams p) {
     typedef _Float16 T;
     static_assert(WM * WN == 8, "eight waves per workgroup");
@@ -222,12 +226,14 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
         static_assert(!FUSE2 || (WM == 2 && WN == 4 && TM == 4 && TP == 4 && 2 * LDS_BYTES <= 163840), "back-to-back 1x1: 128 x 256 tile, two per CU");
         conv_epilogue_fused_1x1<0, false>(p, acc, m0, wm, wn, wave, lane, smem);      // (the stride-2 conv into a stage: no residual)
     } else
-    if (p.out_f32 && !p.vec_out && p.outmode == OUT_NORMAL && !p.has_res) {      // head conv: coalesced float32 rows via LDS
+    if constexpr (EPI == 2) {      // head conv: coalesced float32 rows via LDS
         static_assert(8 * 16 * kStagePitch(TM) * 4 + NB * kStageFlagAnchors * 4 <= S * TILE_BYTES, "staging slabs + row flags must fit in the ring");
         __syncthreads();            // every wave is done reading the ring
         conv_epilogue_f32_staged<TM, TP, 0, true>(p, acc, n0 + wm * (TM * 16), m0 + wn * (TP * 16), lane,
                                          reinterpret_cast<float *>(smem) + wave * 16 * kStagePitch(TM),
                                          reinterpret_cast<float *>(smem) + 8 * 16 * kStagePitch(TM), wn * (TP * 16));
+    } else if constexpr (EPI == 1) {    // (plain fp16 output map, aligned views below 2 GiB)
+        conv_epilogue_fast<TM, TP, 0>(p, acc, n0 + wm * (TM * 16) + fq * CH, m0 + wn * (TP * 16), fr);
     } else {
         conv_epilogue<T, TM, TP, 0, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, m0 + wn * (TP * 16), fr);
     }
@@ -428,6 +434,13 @@ const char *dma_cfg_name(int cfg) { return cfg > 0 && cfg < kNumCfgs ? kCfgs[cfg
     X(14, 2, 4, 4, 2, 3, 4, 6) \
     X(19, 2, 4, 4, 3, 4, 8, 2)
 
+// the epilogue instantiation a launch runs (see the kernel's EPI): 2 = float32 head rows, 1 = lean fp16, 0 = generic
+static inline int dma_epilogue_kind(const ConvParams &p) {
+    if (p.out_f32 && !p.vec_out && p.outmode == OUT_NORMAL && !p.has_res) return 2;
+    static const bool no_fast_epi = getenv("YOLO_NO_FAST_EPI") != nullptr;        // A/B switch, read once (same results either way)
+    return !no_fast_epi && conv_fast_epilogue_ok(p) ? 1 : 0;
+}
+
 static hipError_t launch_dma_tile(const ConvParams &p, int cfg, hipStream_t s) {
     const dim3 grid((unsigned)p.n_blocks), block(512);
     if (p.fuse2) {          // back-to-back 1x1: the 128 x 256 K32 tile
@@ -436,7 +449,11 @@ static hipError_t launch_dma_tile(const ConvParams &p, int cfg, hipStream_t s) {
         return hipGetLastError();
     }
     switch (cfg) {
-#define X(id, ...) case id: hipLaunchKernelGGL((conv_igemm_dma_kernel<__VA_ARGS__>), grid, block, 0, s, p); break;
+#define X(id, ...) case id: \
+        if (dma_epilogue_kind(p) == 2) hipLaunchKernelGGL((conv_igemm_dma_kernel<__VA_ARGS__, false, 2>), grid, block, 0, s, p); \
+        else if (dma_epilogue_kind(p) == 1) hipLaunchKernelGGL((conv_igemm_dma_kernel<__VA_ARGS__, false, 1>), grid, block, 0, s, p); \
+        else hipLaunchKernelGGL((conv_igemm_dma_kernel<__VA_ARGS__, false, 0>), grid, block, 0, s, p); \
+        break;
         YOLO_DMA_VARIANTS(X)
 #undef X
     default: return hipErrorInvalidValue;
@@ -522,10 +539,16 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
 }
 
 std::string dma_cfg_symbol_for(int cfg, bool f32, const ConvParams &p) {
-    if (p.fuse2) return cfg == 6 ? "void yolo::conv_igemm_dma_kernel<2, 4, 4, 4, 3, 4, 4, true>(yolo::ConvParams)"
+    if (p.fuse2) return cfg == 6 ? "void yolo::conv_igemm_dma_kernel<2, 4, 4, 4, 3, 4, 4, true, 0>(yolo::ConvParams)"
                                  : "void yolo::conv3x3_tap_kernel<false, 2, 4, 4, 4, 27, 4, 2, false, true, true>(yolo::ConvParams)";
     if (is_tap_cfg(cfg) && conv_tap_stream_ok(p, tap_variant(cfg))) return conv_tap_stream_symbol(tap_variant(cfg));
-    std::string sym = dma_cfg_symbol(cfg, f32, is_tap_cfg(cfg) && !f32 && conv_fast_epilogue_ok(p) && cfg != 20);
+    if (!is_tap_cfg(cfg)) {     // the LDS-DMA kernel: last template argument = the epilogue kind of this launch
+        std::string sym = dma_cfg_symbol(cfg, f32, false);
+        const size_t at = sym.rfind(", false, 0>(");
+        if (at != std::string::npos) sym[at + 9] = (char)('0' + dma_epilogue_kind(p));
+        return sym;
+    }
+    std::string sym = dma_cfg_symbol(cfg, f32, !f32 && conv_fast_epilogue_ok(p) && cfg != 20);
     if (is_tap_cfg(cfg) && p.outmode == OUT_POOL2) {        // the fused-pool instantiation: template argument MODE 3 instead of 2
         const size_t at = sym.rfind(", 2, false, false, false>(");
         if (at != std::string::npos) sym.replace(at, 26, ", 3, false, false, false>(");
@@ -537,7 +560,8 @@ std::string dma_cfg_symbol_for(int cfg, bool f32, const ConvParams &p) {
 const char *dma_cfg_symbol(int cfg, bool f32, bool fast) {
     if (is_tap_cfg(cfg)) return conv_tap_symbol(tap_variant(cfg), f32, fast);
     switch (cfg) {
-#define X(id, ...) case id: return "void yolo::conv_igemm_dma_kernel<" #__VA_ARGS__ ", false>(yolo::ConvParams)";
+#define X(id, ...) case id: return fast ? "void yolo::conv_igemm_dma_kernel<" #__VA_ARGS__ ", false, 1>(yolo::ConvParams)" \
+                                          : "void yolo::conv_igemm_dma_kernel<" #__VA_ARGS__ ", false, 0>(yolo::ConvParams)";
         YOLO_DMA_VARIANTS(X)
 #undef X
     default: return "";

@@ -793,7 +793,7 @@ hipError_t launch_conv_tap(const ConvParams &p0, int variant, hipStream_t s) {
     ConvParams p = p0;
     static const bool no_fast_epi = getenv("YOLO_NO_FAST_EPI") != nullptr;        // A/B switch, read once (same results either way)
     // (variant 10, the two-per-CU stride-2 tile: its lean instantiation spills 13 registers at the 128-register limit; the generic one does not)
-    p.fast_epi = !no_fast_epi && conv_fast_epilogue_ok(p) && variant != 10 ? 1 : 0;
+    p.fast_epi = (!no_fast_epi || p.fuse2) && conv_fast_epilogue_ok(p) && variant != 10 ? 1 : 0;      // (the fused pair exists in the lean form only)
     const bool s2 = conv_tap_stride2(variant);
     if (p.ksize != 3 || p.stride != (s2 ? 2 : 1) || p.pad != 1 || (p.cin_chunks & 3) || !conv_tap_fits(variant, p.W) || (p.f32 && !conv_tap_f32_ok(variant)))
         return hipErrorInvalidValue;

@@ -472,7 +472,7 @@ def test_back_to_back_1x1_fusion(case, monkeypatch):
     assert sum("+1x1" in n for n in names) == 1 and sum("fused into the conv in front" in n for n in names) == 1, names
     host = next(i for i, n in enumerate(names) if "+1x1" in n)
     assert "fused into the conv in front" in names[host + 1] and syms[host + 1] == ""
-    assert ("conv_igemm_dma_kernel<2, 4, 4, 4, 3, 4, 4, true>" if case == "stride2_into_stage" else
+    assert ("conv_igemm_dma_kernel<2, 4, 4, 4, 3, 4, 4, true, 0>" if case == "stride2_into_stage" else
             "conv3x3_tap_kernel<false, 2, 4, 4, 4, 27, 4, 2, false, true, true>") in syms[host], syms[host]
     fused = eng.forward(x).cpu().numpy()
     assert np.array_equal(fused, eng.forward(x).cpu().numpy())
