@@ -266,7 +266,7 @@ bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile) {
     if (k.outmode == OUT_POOL2 && tile != 12 && tile != 13 && tile != 17) return false;      // the fused max-pool lives in the 16 x 16 2-D tap tiles
     if (tile == 0) return true;
     if (net->opt.dtype == YOLO_DTYPE_F32 && !dma_cfg_f32_ok(tile)) return false;
-    if ((tile == 18 || tile == 21) && k.in.H != k.in.W) return false;     // the image-aligned tap tiles: square maps (the rules price tiles by W alone)
+    if ((tile == 18 || tile == 21 || tile == 22) && k.in.H != k.in.W) return false;     // the image-aligned tap tiles: square maps (the rules price tiles by W alone)
     if ((tile == 20 || tile == 21) && ((k.in.H & 1) || net->opt.dtype != YOLO_DTYPE_F16)) return false;      // stride 2 over parity planes: even maps, fp16
     return dma_eligible(net, k) && dma_cfg_valid(tile, k.cout, k.cpt, true, k.ksize, k.stride, k.in.W);
 }
@@ -326,6 +326,7 @@ ConvPick pick_conv(const yolo_net *net, const Kernel &k, const ConvParams &p, in
     else if (tile < 0) {
         tile = choose_dma_cfg(p.M, k.cout, k.cpt, p.taps, k.has_res, true, k.stride, k.in.W, net->opt.dtype == YOLO_DTYPE_F32);
         if (tile == 18 && !conv_tile_valid(net, k, 18)) tile = conv_tile_valid(net, k, 15) ? 15 : 8;
+        if (tile == 22 && !conv_tile_valid(net, k, 22)) tile = conv_tile_valid(net, k, 10) ? 10 : 8;
         if ((tile == 20 || tile == 21) && !conv_tile_valid(net, k, tile)) tile = conv_tile_valid(net, k, 20) ? 20 : conv_tile_valid(net, k, 5) ? 5 : 0;
     }
     int ku = 0;
@@ -351,9 +352,14 @@ ConvPick pick_conv(const yolo_net *net, const Kernel &k, const ConvParams &p, in
         // per tap for 1 MFLOP: two half-K workgroups on a CU were measured no faster than one whole-K one), the wider tile halves
         // the weight bytes per flop
         const long long b8 = (mq + 255) / 256 * ct, b11 = (mq + 127) / 128 * ct;
+        const long long b22 = (long long)(p.M / p.HoWo) * ct;        // image-aligned 128 x 192 tile: a tile per image and cout tile
         // (that instantiation is built for ONE workgroup per CU -- it needs 180 registers --, so at most 128 tiles = 256 half-K workgroups:
         // 26 x 26 at batch 16 = 184 tiles ran 48 us as 368 halves against 33 us whole)
-        if (units >= 8 && !p.f32 && conv_tile_valid(net, k, 8) && b8 >= 64 && b8 <= 128 && (size_t)b8 * 2 * 131072 <= slab_bytes) {
+        // (12 x 12 / 13 x 13 maps: one image per 192-position tile -- 5 % padding where 256-position tiles of the padded-linear grid
+        // compute 23 %, and 16 images x 8 cout tiles x 2 halves are exactly 256 workgroups: YOLOv2-416 b16 13 x 13 layers -25 %)
+        if (units >= 8 && !p.f32 && conv_tile_valid(net, k, 22) && b22 >= 64 && b22 <= 128 && (size_t)b22 * 2 * 98304 <= slab_bytes) {
+            tile = 22; ks = 2; ku = (units + 1) / 2; pair = 1;
+        } else if (units >= 8 && !p.f32 && conv_tile_valid(net, k, 8) && b8 >= 64 && b8 <= 128 && (size_t)b8 * 2 * 131072 <= slab_bytes) {
             tile = 8; ks = 2; ku = (units + 1) / 2; pair = 1;
         } else if (units >= 8 && conv_tile_valid(net, k, 11) && b11 > 128 && b11 <= 256 && (size_t)b11 * 2 * 65536 <= slab_bytes) {
             tile = 11; ks = 2; ku = (units + 1) / 2; pair = 1;
@@ -396,7 +402,8 @@ size_t splitk_slab_bytes(const yolo_net *net) {
             if (pk.pair) {
                 const long long mq = (long long)(p.M / p.HoWo) * (p.H + 1) * (p.W + 1);
                 const int nb = dma_cfg_nb(pk.tile);
-                const size_t bytes = (size_t)((mq + nb - 1) / nb * ((p.Cout + 127) / 128)) * 2 * 128 * (size_t)nb * 4;
+                const long long ptiles = pk.tile == 22 ? (long long)(p.M / p.HoWo) : (mq + nb - 1) / nb;      // (22: a tile per image)
+                const size_t bytes = (size_t)(ptiles * ((p.Cout + 127) / 128)) * 2 * 128 * (size_t)nb * 4;
                 if (bytes > need) need = bytes;
             } else if (pk.ks > 1) {
                 const size_t bytes = (size_t)pk.ks * (size_t)p.M * (size_t)((p.Cout + 127) / 128 * 128) * 4;

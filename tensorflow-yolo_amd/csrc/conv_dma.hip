@@ -279,10 +279,11 @@ static const DmaCfg kCfgs[] = {
     {128, 192, 1, 1.00f, "128x192,K64,S4", 8},         // 19: conv_dma again: the whole LDS as a four-stage ring (120 KiB in flight), for one-round 1x1 layers on small maps
     {128, 256, 2, 1.00f, "128x256,tap9,s2,x2", 4},     // 20: conv_tap.hip variant 10: 3x3 / stride 2 with tap reuse over the input's parity planes
     {128, 384, 1, 1.00f, "128x384,tap9,s2,img", 4},    // 21: conv_tap.hip variant 11: ... one whole (19 x 19) output image per tile
+    {128, 192, 2, 1.00f, "128x192,tap9,img,x2", 4},    // 22: conv_tap.hip variant 12: one whole 12 x 12 / 13 x 13 image per tile (stride 1)
 };
-static const int kNumCfgs = 22;
+static const int kNumCfgs = 23;
 static const int kFirstTapCfg = 8, kLastTapCfg = 13;
-static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || (cfg >= 15 && cfg <= 18) || cfg == 20 || cfg == 21; }
+static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || (cfg >= 15 && cfg <= 18) || (cfg >= 20 && cfg <= 22); }
 static inline int tap_variant(int cfg) { return cfg >= 20 ? cfg - 10 : cfg >= 15 ? cfg - 9 : cfg - kFirstTapCfg; }     // conv_tap.hip variant of a tap cfg
 bool dma_cfg_is_tap(int cfg) { return is_tap_cfg(cfg); }
 bool dma_cfg_f32_ok(int cfg) { return is_tap_cfg(cfg) && conv_tap_f32_ok(tap_variant(cfg)); }
@@ -333,6 +334,7 @@ static const TileCost kCost[] = {
     {0.60f, 0.60f, 0.60f, 12.0f},       // 19: 128x192 K64 S4
     {1.20f, 1.45f, 0.76f, 7.9f},        // 20: 128x256 stride-2 tap reuse, two per CU (as tile 8)
     {0.90f, 0.90f, 0.90f, 18.0f},       // 21: 128x384 image-aligned stride-2 tap reuse (as tile 18)
+    {0.94f, 1.32f, 0.68f, 8.5f},        // 22: 128x192 image-aligned tap reuse, two per CU (as tile 10)
 };
 
 int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W, bool tap_only) {

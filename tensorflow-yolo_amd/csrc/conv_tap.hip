@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     static_assert(JA_TOT % NW == 0 || JA_TOT < NW, "weight tile must split evenly over the waves (or be smaller than them)");
     static_assert(!TWO_D || PRG * 16 >= (NB / 16 + 2) * PW, "patch buffer too small for the 2-D tile");
     if constexpr (F32 && (TP > 2 || OCC >= 6)) return;     // never launched (launch_conv_tap refuses): no registers for the second accumulator
-    if constexpr (SPLITK && !(WM == 2 && WN == 4 && TM == 4 && (TP == 2 || (TP == 4 && !F32)) && MODE == 1)) return;    // split-K: the 128 x 128 tile; 128 x 256 (fp16) for the in-launch pair
+    if constexpr (SPLITK && !(WM == 2 && WN == 4 && TM == 4 && (TP == 2 || ((TP == 4 || TP == 3) && !F32)) && MODE == 1)) return;    // split-K: the 128 x 128 tile; 128 x 256 and 128 x 192 (fp16) for the in-launch pair
     if constexpr (MODE == 3 && (TP % 2 != 0 || SPLITK)) return;      // split-K: the 128 x 128 tile only
     static_assert(!FAST || (!F32 && !SPLITK && MODE != 3), "the lean epilogue: fp16, whole K, plain output");
     static_assert(!S2 || (!FUSE2 && JA_TOT % NW == 0), "stride 2: every wave carries weights");
@@ -701,14 +701,17 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_stream_kernel(const Conv
 // padding instead of 10.8 %) and 19 x 19 at batch 32 is 32 x 8 = 256 tiles: every CU busy, 14 % less work per CU than the 232 tiles
 // of variant 6
 // 10 = 128 x 256 and 11 = 128 x 384 image-aligned for 3x3 / STRIDE 2 (MODE 4: parity planes of the input, see the kernel): fp16 only
-static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224, 128, 256, 384, 256, 384};
-static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17, 12, 27, 27, 21, 26};
-static const int kTapVariants = 12;
-static const bool kTapF32[] = {false, false, false, true, false, true, false, false, true, false, false, false};      // float32 tiles: TP <= 2 (second-level accumulator)
-bool conv_tap_image_aligned(int variant) { return variant == 9 || variant == 11; }
+// 12 = 128 x 192 image-aligned: one 12 x 12 or 13 x 13 image per tile (YOLOv2-416 / YOLOv3-416 tails: 13 x 14 = 182 of 192 positions
+// real, where 256-position tiles of the padded-linear grid compute 23 % padding); with the in-launch pair split 16 images x 8 cout
+// tiles x 2 K halves = 256 workgroups
+static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224, 128, 256, 384, 256, 384, 192};
+static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17, 12, 27, 27, 21, 26, 14};
+static const int kTapVariants = 13;
+static const bool kTapF32[] = {false, false, false, true, false, true, false, false, true, false, false, false, false};      // float32 tiles: TP <= 2 (second-level accumulator)
+bool conv_tap_image_aligned(int variant) { return variant == 9 || variant == 11 || variant == 12; }
 bool conv_tap_stride2(int variant) { return variant == 10 || variant == 11; }
 bool conv_tap_splitk_ok(int variant) { return variant == 3; }      // the 128 x 128 tile has the (two-pass) split-K instantiation
-bool conv_tap_pair_ok(int variant, bool f32) { return variant == 3 || (variant == 0 && !f32); }   // in-launch pair split: also the fp16 128 x 256 tile
+bool conv_tap_pair_ok(int variant, bool f32) { return variant == 3 || ((variant == 0 || variant == 12) && !f32); }   // in-launch pair split: also the fp16 128 x 256 and image-aligned 128 x 192 tiles
 bool conv_tap_is2d(int variant) { return variant == 4 || variant == 5 || variant == 7 || variant == 8; }
 bool conv_tap_f32_ok(int variant) { return variant >= 0 && variant < kTapVariants && kTapF32[variant]; }
 bool conv_tap_fits(int variant, int W) {
@@ -738,7 +741,8 @@ bool conv_tap_fits(int variant, int W) {
     X(8, 1, 8, 2, 2, 27, 4, 2) \
     X(9, 2, 4, 4, 6, 27, 2, 1) \
     X(10, 2, 4, 4, 4, 21, 4, 4) \
-    X(11, 2, 4, 4, 6, 26, 2, 4)
+    X(11, 2, 4, 4, 6, 26, 2, 4) \
+    X(12, 2, 4, 4, 3, 14, 4, 1)
 
 const char *conv_tap_symbol(int variant, bool f32, bool fast) {
     switch (variant) {
@@ -814,6 +818,7 @@ hipError_t launch_conv_tap(const ConvParams &p0, int variant, hipStream_t s) {
         // (OCC 2 = up to 256 registers: the pair launches are <= 512 workgroups of half K on 256 CUs, and the 128 x 256 tile + the
         // hand-off state spills at the 128 registers of two-per-CU residency)
         if (variant == 0) hipLaunchKernelGGL((conv3x3_tap_kernel<false, 2, 4, 4, 4, 26, 2, 1, true>), grid, dim3(512), 0, s, p);
+        else if (variant == 12) hipLaunchKernelGGL((conv3x3_tap_kernel<false, 2, 4, 4, 3, 14, 2, 1, true>), grid, dim3(512), 0, s, p);
         else if (p.f32) hipLaunchKernelGGL((conv3x3_tap_kernel<true, 2, 4, 4, 2, 28, 4, 1, true>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv3x3_tap_kernel<false, 2, 4, 4, 2, 28, 4, 1, true>), grid, dim3(512), 0, s, p);
         return hipGetLastError();

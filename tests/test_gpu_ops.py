@@ -336,9 +336,9 @@ def test_tap_reuse_tile_configs(tile):
     assert "tap9" in names, names
 
 
-@pytest.mark.parametrize("shape", [(2, 19, 19, 512, 256), (3, 38, 38, 64, 128), (1, 76, 76, 128, 256), (2, 7, 78, 32, 128),
+@pytest.mark.parametrize("shape", [(2, 19, 19, 512, 256), (5, 13, 13, 128, 256), (3, 38, 38, 64, 128), (1, 76, 76, 128, 256), (2, 7, 78, 32, 128),
                                    (2, 5, 110, 64, 128), (1, 9, 152, 64, 128), (2, 33, 100, 32, 64), (1, 48, 304, 32, 64), (2, 21, 70, 32, 32)])
-@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15, 16, 17, 18])
+@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 22])
 def test_tap_reuse_conv_shapes(shape, tile):
     """conv_tap.hip on the feature-map sizes of YOLOv3-608 (19, 38, 76), the widest rows its padded-linear tiles take
     (78, 110, 158 >= 152), wide maps for the 2-D tiles (partial 16x16 tiles in both directions, Cout 64) and a residual
@@ -357,8 +357,8 @@ def test_tap_reuse_conv_shapes(shape, tile):
         if dict(((11, cout > 64 and W <= 158), (13, cout == 64), (17, cout == 32)))[tile]:
             assert "tap9" in " ".join(ki.name.decode() for ki in eng32.kernel_infos())
     names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
-    max_w = {8: 78, 9: 78, 10: 110, 11: 158, 12: 1 << 20, 13: 1 << 20, 15: 22, 16: 1 << 20, 17: 1 << 20, 18: 19}[tile]
-    need = {8: cout > 64, 9: cout >= 256, 10: cout > 64, 11: cout > 64, 12: cout > 64, 13: cout == 64, 15: cout >= 256, 16: cout > 64, 17: cout == 32, 18: cout > 64 and H == W and W >= 17}[tile]
+    max_w = {8: 78, 9: 78, 10: 110, 11: 158, 12: 1 << 20, 13: 1 << 20, 15: 22, 16: 1 << 20, 17: 1 << 20, 18: 19, 22: 13}[tile]
+    need = {8: cout > 64, 9: cout >= 256, 10: cout > 64, 11: cout > 64, 12: cout > 64, 13: cout == 64, 15: cout >= 256, 16: cout > 64, 17: cout == 32, 18: cout > 64 and H == W and W >= 18, 22: cout > 64 and H == W and W >= 12}[tile]
     if W <= max_w and need:             # else: the forced tile is not valid for this layer, the default one runs
         assert "tap9" in names, names
 
@@ -505,13 +505,15 @@ def test_in_launch_pair_split_k(dtype, shape):
     syms = [ki.symbol.decode() for ki in infos]
     pair = [i for i, n in enumerate(names) if "+pairK" in n]
     assert len(pair) == 2, names
-    want_sym = "conv3x3_tap_kernel<false, 2, 4, 4, 4, 26, 2, 1, true, false, false>" if dtype == "fp16" else "conv3x3_tap_kernel<true, 2, 4, 4, 2, 28, 4, 1, true, false, false>"
+    # (13 x 13, fp16: the image-aligned 128 x 192 tile -- one image per tile, 24 images x 4 cout tiles x 2 halves)
+    want_sym = ("conv3x3_tap_kernel<false, 2, 4, 4, 3, 14, 2, 1, true, false, false>" if dtype == "fp16" and H == 13 else
+                "conv3x3_tap_kernel<false, 2, 4, 4, 4, 26, 2, 1, true, false, false>" if dtype == "fp16" else "conv3x3_tap_kernel<true, 2, 4, 4, 2, 28, 4, 1, true, false, false>")
     assert all(want_sym in syms[i] for i in pair), syms
     a = eng.forward(x).cpu().numpy()
     b = eng.forward(x).cpu().numpy()
     c = eng.forward(x[:B]).cpu().numpy()
     assert np.array_equal(a, b) and np.array_equal(a, c), "the pair launch is not repeatable: a ticket counter did not return to zero"
-    tile = 8 if dtype == "fp16" else 11
+    tile = (22 if H == 13 else 8) if dtype == "fp16" else 11
     whole, eng_w = run_hip(g, synth.darknet_stream(g, seed=12), x, dtype, force_tile=tile)
     assert not any("+pairK" in ki.name.decode() for ki in eng_w.kernel_infos()), "a forced tile must run as it is named"
     assert rel_err(a, whole) <= (2e-3 if dtype == "fp16" else 2e-6)        # same products, K summed in two halves
