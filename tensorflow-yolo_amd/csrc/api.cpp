@@ -834,6 +834,8 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
                 if (at != std::string::npos) sym.replace(at, 23, ", true, false, false>(");
                 const size_t occ = sym.find("26, 4, 1, true, false, false>(");       // the in-launch pair on the 128 x 256 tile is built for one workgroup per CU
                 if (pk.pair && occ != std::string::npos) sym.replace(occ, 30, "26, 2, 1, true, false, false>(");
+                const size_t occ22 = sym.find("14, 4, 1, true, false, false>(");     // ... and on the image-aligned 128 x 192 tile
+                if (pk.pair && occ22 != std::string::npos) sym.replace(occ22, 30, "14, 2, 1, true, false, false>(");
             }
             set_symbol(sym);
         } else {
