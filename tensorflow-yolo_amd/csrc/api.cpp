@@ -267,7 +267,6 @@ bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile) {
     if (tile == 0) return true;
     if (net->opt.dtype == YOLO_DTYPE_F32 && !dma_cfg_f32_ok(tile)) return false;
     if ((tile == 18 || tile == 21 || tile == 22) && k.in.H != k.in.W) return false;     // the image-aligned tap tiles: square maps (the rules price tiles by W alone)
-    if (tile == 23 && (k.head || k.out.f32 || net->opt.dtype != YOLO_DTYPE_F16)) return false;      // pixel operand in registers: fp16 1x1 layers behind which more layers follow
     if ((tile == 20 || tile == 21) && ((k.in.H & 1) || net->opt.dtype != YOLO_DTYPE_F16)) return false;      // stride 2 over parity planes: even maps, fp16
     return dma_eligible(net, k) && dma_cfg_valid(tile, k.cout, k.cpt, true, k.ksize, k.stride, k.in.W);
 }

@@ -280,9 +280,8 @@ static const DmaCfg kCfgs[] = {
     {128, 256, 2, 1.00f, "128x256,tap9,s2,x2", 4},     // 20: conv_tap.hip variant 10: 3x3 / stride 2 with tap reuse over the input's parity planes
     {128, 384, 1, 1.00f, "128x384,tap9,s2,img", 4},    // 21: conv_tap.hip variant 11: ... one whole (19 x 19) output image per tile
     {128, 192, 2, 1.00f, "128x192,tap9,img,x2", 4},    // 22: conv_tap.hip variant 12: one whole 12 x 12 / 13 x 13 image per tile (stride 1)
-    {128, 256, 2, 1.00f, "128x256,1x1,regB,x2", 8},    // 23: conv_1x1.hip: 1x1 convs, pixel operand per lane into registers, weights alone in the ring
 };
-static const int kNumCfgs = 24;
+static const int kNumCfgs = 23;
 static const int kFirstTapCfg = 8, kLastTapCfg = 13;
 static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || (cfg >= 15 && cfg <= 18) || (cfg >= 20 && cfg <= 22); }
 static inline int tap_variant(int cfg) { return cfg >= 20 ? cfg - 10 : cfg >= 15 ? cfg - 9 : cfg - kFirstTapCfg; }     // conv_tap.hip variant of a tap cfg
@@ -296,7 +295,6 @@ bool dma_cfg_valid(int cfg, int cout, int cin_chunks, bool v1_ok, int ksize, int
     if (cfg < 0 || cfg >= kNumCfgs) return false;
     const DmaCfg &k = kCfgs[cfg];
     if (cin_chunks % k.bkc) return false;
-    if (cfg == 23 && (ksize != 1 || stride != 1)) return false;
     if (is_tap_cfg(cfg) && (ksize != 3 || stride != (conv_tap_stride2(tap_variant(cfg)) ? 2 : 1) || !conv_tap_fits(tap_variant(cfg), W))) return false;
     if (k.na == 32) return cout <= 32 && cout > 16;
     if (k.na == 64) return cout <= 64 && (!is_tap_cfg(cfg) || cout > 32);
@@ -337,7 +335,6 @@ static const TileCost kCost[] = {
     {1.20f, 1.45f, 0.76f, 7.9f},        // 20: 128x256 stride-2 tap reuse, two per CU (as tile 8)
     {0.90f, 0.90f, 0.90f, 18.0f},       // 21: 128x384 image-aligned stride-2 tap reuse (as tile 18)
     {0.94f, 1.32f, 0.68f, 8.5f},        // 22: 128x192 image-aligned tap reuse, two per CU (as tile 10)
-    {0.0f, 0.0f, 0.0f, 0.0f},           // 23: 1x1 with the pixel operand in registers (chosen by rule)
 };
 
 int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W, bool tap_only) {
@@ -385,7 +382,7 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
         const long long wg128 = (long long)((M + 127) / 128) * ((cout + 127) / 128);
         if (c == 14 && taps != 1 && !(stride == 2 && wg128 > 128 && wg128 <= 256)) continue;
         if (c == 19 && taps != 1) continue;     // (measured on 1x1 layers only)
-        if (c == 7 || c == 13 || c == 16 || c == 17 || c == 23 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
+        if (c == 7 || c == 13 || c == 16 || c == 17 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
         const DmaCfg &k = kCfgs[c];
         // tap-reuse tiles walk the padded position grid: (H+1)(W+1) positions per image (square maps assumed here)
         long long Meff = M;
@@ -447,7 +444,6 @@ static inline int dma_epilogue_kind(const ConvParams &p) {
 }
 
 static hipError_t launch_dma_tile(const ConvParams &p, int cfg, hipStream_t s) {
-    if (cfg == 23) return launch_conv_1x1_regb(p, s);
     const dim3 grid((unsigned)p.n_blocks), block(512);
     if (p.fuse2) {          // back-to-back 1x1: the 128 x 256 K32 tile
         if (cfg != 6 || !conv_fast_epilogue_ok(p) || p.has_res || p.n_tiles_n != 1 || p.Cout != 128 || !p.w2 || !p.b2 || !p.out2 || !p.out2_bytes) return hipErrorInvalidValue;
@@ -548,7 +544,6 @@ std::string dma_cfg_symbol_for(int cfg, bool f32, const ConvParams &p) {
     if (p.fuse2) return cfg == 6 ? "void yolo::conv_igemm_dma_kernel<2, 4, 4, 4, 3, 4, 4, true, 0>(yolo::ConvParams)"
                                  : "void yolo::conv3x3_tap_kernel<false, 2, 4, 4, 4, 27, 4, 2, false, true, true>(yolo::ConvParams)";
     if (is_tap_cfg(cfg) && conv_tap_stream_ok(p, tap_variant(cfg))) return conv_tap_stream_symbol(tap_variant(cfg));
-    if (cfg == 23) return conv_1x1_regb_symbol(conv_fast_epilogue_ok(p));
     if (!is_tap_cfg(cfg)) {     // the LDS-DMA kernel: last template argument = the epilogue kind of this launch
         std::string sym = dma_cfg_symbol(cfg, f32, false);
         const size_t at = sym.rfind(", false, 0>(");

@@ -274,10 +274,6 @@ int dma_cfg_bkc(int cfg);
 hipError_t launch_conv_dma(const ConvParams &p, int cfg, hipStream_t s);
 hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s);       // conv_tap.hip: 3x3/1 with tap reuse
 bool conv_tap_stream_ok(const ConvParams &p, int variant);                         // the persistent form takes this launch
-// conv_1x1.hip: 1x1 conv with the pixel operand loaded per lane into the MFMA B fragment (tile id 23)
-bool conv_1x1_regb_ok(const ConvParams &p);
-const char *conv_1x1_regb_symbol(bool fast);
-hipError_t launch_conv_1x1_regb(const ConvParams &p, hipStream_t s);
 bool conv_tap_fits(int variant, int W);
 bool conv_tap_is2d(int variant);
 bool conv_tap_stride2(int variant);         // 3x3 / stride 2 over the input's parity planes (MODE 4)
