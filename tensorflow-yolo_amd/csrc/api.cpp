@@ -365,6 +365,17 @@ ConvPick pick_conv(const yolo_net *net, const Kernel &k, const ConvParams &p, in
             tile = 11; ks = 2; ku = (units + 1) / 2; pair = 1;
         }
     }
+    // Split-K on the 128 x 128 tap tile (small maps at batch 1-4: a handful of tiles, K in up to 32 splits): the splits meet INSIDE the
+    // launch -- ticket per tile, the last arriver sums every split's slab in split order and runs the fused epilogue (conv_tap.hip) --
+    // instead of in a splitk_reduce_kernel launch of its own (YOLOv3-608 at batch 1: 20 of 95 launches).
+    static const bool no_inl = getenv("YOLO_NO_INLAUNCH_SPLITK") != nullptr;      // A/B switch (same results up to the fp32 summation order of the splits)
+    // (up to eight splits: ONE workgroup reads them all -- 38 x 38 at batch 1, 2 splits: 23 -> 20 us; 19 x 19, 8 splits: 25.5 -> 24; beyond
+    // that the reduce launch, which spreads the sum over the chip, wins: 13 x 13 float32 with 16 / 32 splits 38 -> 40.5 / 61 -> 67 us)
+    if (ks > 1 && ks <= 8 && !pair && tile == 11 && !no_inl) {
+        const long long mq = (long long)(p.M / p.HoWo) * (p.H + 1) * (p.W + 1);
+        const long long nb11 = (mq + 127) / 128 * ((p.Cout + 127) / 128);
+        if (nb11 * 4 <= (long long)kPairCounterBytes && (size_t)nb11 * (size_t)ks * 65536 <= slab_bytes) pair = 1;
+    }
     return ConvPick{tile, ks, ku, pair};
 }
 
@@ -403,7 +414,7 @@ size_t splitk_slab_bytes(const yolo_net *net) {
                 const long long mq = (long long)(p.M / p.HoWo) * (p.H + 1) * (p.W + 1);
                 const int nb = dma_cfg_nb(pk.tile);
                 const long long ptiles = pk.tile == 22 ? (long long)(p.M / p.HoWo) : (mq + nb - 1) / nb;      // (22: a tile per image)
-                const size_t bytes = (size_t)(ptiles * ((p.Cout + 127) / 128)) * 2 * 128 * (size_t)nb * 4;
+                const size_t bytes = (size_t)(ptiles * ((p.Cout + 127) / 128)) * (size_t)pk.ks * 128 * (size_t)nb * 4;
                 if (bytes > need) need = bytes;
             } else if (pk.ks > 1) {
                 const size_t bytes = (size_t)pk.ks * (size_t)p.M * (size_t)((p.Cout + 127) / 128 * 128) * 4;
@@ -851,10 +862,11 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
             const size_t n = strlen(out->name);
             snprintf(out->name + n, sizeof out->name - n, "+1x1");
         }
-        if (pk.pair) {              // K in two halves inside the launch
+        if (pk.pair) {              // K in two halves (or pk.ks splits) inside the launch
             const size_t n = strlen(out->name);
-            snprintf(out->name + n, sizeof out->name - n, "+pairK");
-            out->bytes += 2.0 * (double)li.H * li.W * ((k.cout + 127) / 128 * 128) * 4.0;
+            if (pk.ks == 2) snprintf(out->name + n, sizeof out->name - n, "+pairK");
+            else snprintf(out->name + n, sizeof out->name - n, "+splitK%d,1launch", pk.ks);
+            out->bytes += (double)pk.ks * (double)li.H * li.W * ((k.cout + 127) / 128 * 128) * 4.0;
         } else if (pk.ks > 1) {     // two launches: K splits into the float32 slab, then splitk_reduce_kernel (sum + fused epilogue)
             const size_t n = strlen(out->name);
             snprintf(out->name + n, sizeof out->name - n, "+splitK%d", pk.ks);

@@ -369,9 +369,13 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         // ticket (relaxed agent-scope atomic); the second arriver acquires (one agent-scope fence by that lane, drained before
         // the barrier that releases the other waves) and reads the first arriver's slab with sc1 loads.  Placement-independent;
         // fp32 addition commutes, so the result does not depend on which half arrives last.  The counter returns to 0.
+        // More than two splits (round 4: the split-K launches of the small maps at batch 1-4 without their reduce launch): the LAST
+        // arriver sums the slabs of ALL splits in split order -- its own included, from memory: fp32 addition is not associative, and the
+        // result must not depend on who arrives last.
         constexpr uint32_t SLAB = (uint32_t)NA * NB * 4;
         const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(p.part, 0, p.part_bytes, 0x00020000);
-        const uint32_t mine = ((uint32_t)blockIdx.x * 2u + blockIdx.y) * SLAB, other = ((uint32_t)blockIdx.x * 2u + (1u - blockIdx.y)) * SLAB;
+        const uint32_t nsplit = gridDim.y;
+        const uint32_t mine = ((uint32_t)blockIdx.x * nsplit + blockIdx.y) * SLAB, other = ((uint32_t)blockIdx.x * nsplit + (1u - blockIdx.y)) * SLAB;
         typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u4;
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -384,7 +388,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         int *const flag = reinterpret_cast<int *>(smem);
         if (tid == 0) {
             const int t = __hip_atomic_fetch_add(p.pair_cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t == 1) {
+            if (t == (int)nsplit - 1) {
                 __hip_atomic_store(p.pair_cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -392,7 +396,27 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
             *flag = t;
         }
         __syncthreads();
-        if (*flag == 0) return;             // first arriver: its half is published
+        if (*flag != (int)nsplit - 1) return;       // not the last arriver: its share is published
+        if (nsplit > 2) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TP; ++b) acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
+            for (uint32_t sp = 0; sp < nsplit; ++sp) {
+                const uint32_t base = ((uint32_t)blockIdx.x * nsplit + sp) * SLAB;
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    u4 v[TP];
+#pragma unroll
+                    for (int b = 0; b < TP; ++b)
+                        v[b] = __builtin_amdgcn_raw_buffer_load_b128(rs_part, base + (uint32_t)((((wave * TM + a) * TP + b) * 64 + lane) * 16), 0, 16 /* sc1 */);
+#pragma unroll
+                    for (int b = 0; b < TP; ++b) acc[a][b] += __builtin_bit_cast(float4v, v[b]);
+                }
+            }
+            conv_epilogue<T, TM, TP, PADQ, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < TM; ++a) {      // TP loads in flight at a time (all TM * TP at once would need 64 more registers)
             u4 v[TP];
@@ -814,7 +838,9 @@ hipError_t launch_conv_tap(const ConvParams &p0, int variant, hipStream_t s) {
         if (!(p.pair ? conv_tap_pair_ok(variant, p.f32 != 0) : conv_tap_splitk_ok(variant)) || !p.part || p.kunits < 1 ||
             (long long)p.ksplit * p.kunits < (p.cin_chunks >> 2))
             return hipErrorInvalidValue;
-        if (p.pair && (p.ksplit != 2 || !p.pair_cnt || (unsigned long long)p.n_blocks * 2ull * 128ull * kTapNB[variant] * 4ull > p.part_bytes)) return hipErrorInvalidValue;
+        if (p.pair && (p.ksplit < 2 || (p.ksplit > 2 && variant != 3) || !p.pair_cnt ||
+                       (unsigned long long)p.n_blocks * (unsigned long long)p.ksplit * 128ull * kTapNB[variant] * 4ull > p.part_bytes))
+            return hipErrorInvalidValue;
         // (OCC 2 = up to 256 registers: the pair launches are <= 512 workgroups of half K on 256 CUs, and the 128 x 256 tile + the
         // hand-off state spills at the 128 registers of two-per-CU residency)
         if (variant == 0) hipLaunchKernelGGL((conv3x3_tap_kernel<false, 2, 4, 4, 4, 26, 2, 1, true>), grid, dim3(512), 0, s, p);

@@ -523,8 +523,8 @@ def test_in_launch_pair_split_k(dtype, shape):
 @pytest.mark.parametrize("batch", [1, 2])
 def test_split_k_small_maps(dtype, batch):
     """13 x 13 / 7 x 9 maps at batch 1-2: a launch is a handful of tiles with K in the thousands, so the K range is split over
-    workgroups (conv_tap.hip channel slices, conv.hip K tiles) and splitk_reduce_kernel sums the float32 partials and runs
-    the epilogue: bias + leaky, fused residual, reorg and upsample output maps, Cout tails (255, 320), float32 final layer"""
+    workgroups (conv_tap.hip channel slices, conv.hip K tiles) and the float32 partials are summed by splitk_reduce_kernel (4-wave
+    kernel) or by the tile's last arriver inside the launch (tap tile), which then runs the epilogue: bias + leaky, fused residual, reorg and upsample output maps, Cout tails (255, 320), float32 final layer"""
     g = new_graph(13, 13, 64)
     g.append(PL.conv2d_bn_act(g[-1].out, 512, 3, 1))                 # 1  3x3 Cin 64
     g.append(PL.conv2d_bn_act(g[-1].out, 1024, 3, 1))                # 2  3x3 Cin 512: K = 4608
@@ -539,4 +539,11 @@ def test_split_k_small_maps(dtype, batch):
     g.append(PL.conv2d_bn_act(g[-1].out, 1024, 3, 1))                # 11
     g.append(PL.conv2d_bn_act(g[-1].out, 255, 1, 1, use_batch_normalization=False, activation_fn="linear"))   # 12 float32 out
     x = synth.synthetic_input(batch, 13, 13, 64, seed=31)
-    check_graph(g, x, dtype, seed=9, read=(2, 5, 6, 8, 10, 11))
+    eng = check_graph(g, x, dtype, seed=9, read=(2, 5, 6, 8, 10, 11))
+    # round 4: the 3x3 / 1 layers on the tap tile sum their splits INSIDE the launch (the last arriver of a tile adds every split's slab
+    # in split order: no reduce launch, and the same bits whoever arrives last)
+    names = [ki.name.decode() for ki in eng.kernel_infos()]
+    assert sum(",1launch" in n or "+pairK" in n for n in names) >= 2, names
+    a = eng.forward(x).cpu().numpy()
+    for _ in range(3):
+        assert np.array_equal(a, eng.forward(x).cpu().numpy()), "in-launch split-K is not repeatable (summation order or ticket counter)"
