@@ -267,7 +267,7 @@ bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile) {
     if (tile == 0) return true;
     if (net->opt.dtype == YOLO_DTYPE_F32 && !dma_cfg_f32_ok(tile)) return false;
     if ((tile == 18 || tile == 21 || tile == 22) && k.in.H != k.in.W) return false;     // the image-aligned tap tiles: square maps (the rules price tiles by W alone)
-    if ((tile == 20 || tile == 21) && ((k.in.H & 1) || net->opt.dtype != YOLO_DTYPE_F16)) return false;      // stride 2 over parity planes: even maps, fp16
+    if ((tile == 20 || tile == 21 || tile == 23) && ((k.in.H & 1) || net->opt.dtype != YOLO_DTYPE_F16)) return false;      // stride 2 over parity planes: even maps, fp16
     return dma_eligible(net, k) && dma_cfg_valid(tile, k.cout, k.cpt, true, k.ksize, k.stride, k.in.W);
 }
 
@@ -328,6 +328,7 @@ ConvPick pick_conv(const yolo_net *net, const Kernel &k, const ConvParams &p, in
         if (tile == 18 && !conv_tile_valid(net, k, 18)) tile = conv_tile_valid(net, k, 15) ? 15 : 8;
         if (tile == 22 && !conv_tile_valid(net, k, 22)) tile = conv_tile_valid(net, k, 10) ? 10 : 8;
         if ((tile == 20 || tile == 21) && !conv_tile_valid(net, k, tile)) tile = conv_tile_valid(net, k, 20) ? 20 : conv_tile_valid(net, k, 5) ? 5 : 0;
+        if (tile == 23 && !conv_tile_valid(net, k, 23)) tile = conv_tile_valid(net, k, 6) ? 6 : 0;
     }
     int ku = 0;
     int ks = choose_ksplit(k, p, tile, slab_bytes, ku);
@@ -435,8 +436,8 @@ bool conv_fuse2(const yolo_net *net, size_t ki, const Ptrs *P, int batch, ConvPa
     const Kernel &k = net->kernels[ki];
     if (!k.fuse2_next || ki + 1 >= net->kernels.size() || !net->kernels[ki + 1].fuse2_prev) return false;
     const ConvPick pk = pick_conv(net, k, p, k.tile, slab_bytes);
-    if ((pk.tile != 12 && pk.tile != 6) || pk.ks > 1 || pk.pair || !conv_fast_epilogue_ok(p)) return false;
-    if ((pk.tile == 12) != (p.has_res != 0)) return false;      // the two instantiations built: tap tile + residual, LDS-DMA tile without
+    if ((pk.tile != 12 && pk.tile != 6 && pk.tile != 23) || pk.ks > 1 || pk.pair || !conv_fast_epilogue_ok(p)) return false;
+    if ((pk.tile == 12) != (p.has_res != 0)) return false;      // the instantiations built: 2-D tap tile + residual; LDS-DMA tile / stride-2 tap tile without
     const Kernel &b = net->kernels[ki + 1];
     const long long ob = (long long)batch * b.out.img_stride * net->esize;
     if (ob <= 0 || ob > 0x7ffffff0LL) return false;

@@ -280,10 +280,11 @@ static const DmaCfg kCfgs[] = {
     {128, 256, 2, 1.00f, "128x256,tap9,s2,x2", 4},     // 20: conv_tap.hip variant 10: 3x3 / stride 2 with tap reuse over the input's parity planes
     {128, 384, 1, 1.00f, "128x384,tap9,s2,img", 4},    // 21: conv_tap.hip variant 11: ... one whole (19 x 19) output image per tile
     {128, 192, 2, 1.00f, "128x192,tap9,img,x2", 4},    // 22: conv_tap.hip variant 12: one whole 12 x 12 / 13 x 13 image per tile (stride 1)
+    {128, 256, 2, 1.00f, "128x256,tap9,s2,wide,x2", 4},   // 23: conv_tap.hip variant 13: tile 20 for output maps up to 158 wide; hosts the back-to-back 1x1
 };
-static const int kNumCfgs = 23;
+static const int kNumCfgs = 24;
 static const int kFirstTapCfg = 8, kLastTapCfg = 13;
-static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || (cfg >= 15 && cfg <= 18) || (cfg >= 20 && cfg <= 22); }
+static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || (cfg >= 15 && cfg <= 18) || (cfg >= 20 && cfg <= 23); }
 static inline int tap_variant(int cfg) { return cfg >= 20 ? cfg - 10 : cfg >= 15 ? cfg - 9 : cfg - kFirstTapCfg; }     // conv_tap.hip variant of a tap cfg
 bool dma_cfg_is_tap(int cfg) { return is_tap_cfg(cfg); }
 bool dma_cfg_f32_ok(int cfg) { return is_tap_cfg(cfg) && conv_tap_f32_ok(tap_variant(cfg)); }
@@ -335,6 +336,7 @@ static const TileCost kCost[] = {
     {1.20f, 1.45f, 0.76f, 7.9f},        // 20: 128x256 stride-2 tap reuse, two per CU (as tile 8)
     {0.90f, 0.90f, 0.90f, 18.0f},       // 21: 128x384 image-aligned stride-2 tap reuse (as tile 18)
     {0.94f, 1.32f, 0.68f, 8.5f},        // 22: 128x192 image-aligned tap reuse, two per CU (as tile 10)
+    {0.0f, 0.0f, 0.0f, 0.0f},           // 23: wide stride-2 tap reuse (chosen by rule)
 };
 
 int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W, bool tap_only) {
@@ -368,6 +370,9 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
     if (tap_only && v1_ok && taps == 9 && stride == 1 && W <= 14 && taps * cin_chunks * 4 >= 4608 &&
         ((long long)M * (W + 1) * (W + 1) / ((long long)W * W) + 127) / 128 * ((cout + 127) / 128) > 512)
         return 0;
+    // (tile 23, the parity-plane tap tile with the back-to-back 1x1 for the stride-2 conv 64 -> 128 into a wide stage, is NOT chosen by
+    // rule: at 304 -> 152, batch 32, it measures 211 us against 208 for LDS-DMA tile 6 with the same fusion -- two channel slices are
+    // too short a K loop for tap reuse to matter, the launch is the 660 MB it moves)
     const double k64 = taps * cin_chunks / 8.0;         // 64-deep K tiles
     int best = fallback;
     double best_t = 1e300;
@@ -382,7 +387,7 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
         const long long wg128 = (long long)((M + 127) / 128) * ((cout + 127) / 128);
         if (c == 14 && taps != 1 && !(stride == 2 && wg128 > 128 && wg128 <= 256)) continue;
         if (c == 19 && taps != 1) continue;     // (measured on 1x1 layers only)
-        if (c == 7 || c == 13 || c == 16 || c == 17 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
+        if (c == 7 || c == 13 || c == 16 || c == 17 || c == 23 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
         const DmaCfg &k = kCfgs[c];
         // tap-reuse tiles walk the padded position grid: (H+1)(W+1) positions per image (square maps assumed here)
         long long Meff = M;
@@ -542,7 +547,8 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
 
 std::string dma_cfg_symbol_for(int cfg, bool f32, const ConvParams &p) {
     if (p.fuse2) return cfg == 6 ? "void yolo::conv_igemm_dma_kernel<2, 4, 4, 4, 3, 4, 4, true, 0>(yolo::ConvParams)"
-                                 : "void yolo::conv3x3_tap_kernel<false, 2, 4, 4, 4, 27, 4, 2, false, true, true>(yolo::ConvParams)";
+                       : cfg == 23 ? "void yolo::conv3x3_tap_kernel<false, 2, 4, 4, 4, 26, 4, 4, false, true, true>(yolo::ConvParams)"
+                                   : "void yolo::conv3x3_tap_kernel<false, 2, 4, 4, 4, 27, 4, 2, false, true, true>(yolo::ConvParams)";
     if (is_tap_cfg(cfg) && conv_tap_stream_ok(p, tap_variant(cfg))) return conv_tap_stream_symbol(tap_variant(cfg));
     if (!is_tap_cfg(cfg)) {     // the LDS-DMA kernel: last template argument = the epilogue kind of this launch
         std::string sym = dma_cfg_symbol(cfg, f32, false);
@@ -550,7 +556,7 @@ std::string dma_cfg_symbol_for(int cfg, bool f32, const ConvParams &p) {
         if (at != std::string::npos) sym[at + 9] = (char)('0' + dma_epilogue_kind(p));
         return sym;
     }
-    std::string sym = dma_cfg_symbol(cfg, f32, !f32 && conv_fast_epilogue_ok(p) && cfg != 20);
+    std::string sym = dma_cfg_symbol(cfg, f32, !f32 && conv_fast_epilogue_ok(p) && cfg != 20 && cfg != 23);
     if (is_tap_cfg(cfg) && p.outmode == OUT_POOL2) {        // the fused-pool instantiation: template argument MODE 3 instead of 2
         const size_t at = sym.rfind(", 2, false, false, false>(");
         if (at != std::string::npos) sym.replace(at, 26, ", 3, false, false, false>(");

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
     if constexpr (SPLITK && !(WM == 2 && WN == 4 && TM == 4 && (TP == 2 || ((TP == 4 || TP == 3) && !F32)) && MODE == 1)) return;    // split-K: the 128 x 128 tile; 128 x 256 and 128 x 192 (fp16) for the in-launch pair
     if constexpr (MODE == 3 && (TP % 2 != 0 || SPLITK)) return;      // split-K: the 128 x 128 tile only
     static_assert(!FAST || (!F32 && !SPLITK && MODE != 3), "the lean epilogue: fp16, whole K, plain output");
-    static_assert(!S2 || (!FUSE2 && JA_TOT % NW == 0), "stride 2: every wave carries weights");
+    static_assert(!S2 || JA_TOT % NW == 0, "stride 2: every wave carries weights");
     if constexpr (S2 && (F32 || SPLITK)) return;            // never launched (launch_conv_tap refuses): fp16, whole K only
     static_assert(!FUSE2 || (FAST && WM == 2 && WN == 4 && TM == 4 && TP == 4), "back-to-back 1x1: the 128 x 256 tiles");
     constexpr int LDS_BYTES = FUSE2 && kFuse2LdsBytes > S * A_BYTES + 2 * P_BYTES ? kFuse2LdsBytes : S * A_BYTES + 2 * P_BYTES;
@@ -434,7 +434,8 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         if constexpr (MODE == 3) conv_epilogue_pool2<T, TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
         else if constexpr (FUSE2) {
             static_assert(!FUSE2 || 2 * LDS_BYTES <= 163840, "two workgroups per CU");
-            conv_epilogue_fused_1x1<PADQ, true>(p, acc, q0, wm, wn, wave, lane, smem);       // (the residual block's 3x3: with residual)
+            if constexpr (S2) conv_epilogue_fused_1x1<PADQ, false>(p, acc, q0, wm, wn, wave, lane, smem);    // (the stride-2 conv into a stage: no residual)
+            else conv_epilogue_fused_1x1<PADQ, true>(p, acc, q0, wm, wn, wave, lane, smem);       // (the residual block's 3x3: with residual)
         }
         else if constexpr (FAST) conv_epilogue_fast<TM, TP, PADQ>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
         else conv_epilogue<T, TM, TP, PADQ, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
@@ -728,12 +729,14 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_stream_kernel(const Conv
 // 12 = 128 x 192 image-aligned: one 12 x 12 or 13 x 13 image per tile (YOLOv2-416 / YOLOv3-416 tails: 13 x 14 = 182 of 192 positions
 // real, where 256-position tiles of the padded-linear grid compute 23 % padding); with the in-launch pair split 16 images x 8 cout
 // tiles x 2 K halves = 256 workgroups
-static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224, 128, 256, 384, 256, 384, 192};
-static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17, 12, 27, 27, 21, 26, 14};
-static const int kTapVariants = 13;
-static const bool kTapF32[] = {false, false, false, true, false, true, false, false, true, false, false, false, false};      // float32 tiles: TP <= 2 (second-level accumulator)
+// 13 = variant 10 with a patch of 26 row groups (output maps up to 158 wide): the stride-2 conv into the 152 x 152 stage, whose
+// workgroups hold all 128 couts of 256 positions -- the one stride-2 tile with the back-to-back 1x1 instantiation (FUSE2)
+static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224, 128, 256, 384, 256, 384, 192, 256};
+static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17, 12, 27, 27, 21, 26, 14, 26};
+static const int kTapVariants = 14;
+static const bool kTapF32[] = {false, false, false, true, false, true, false, false, true, false, false, false, false, false};      // float32 tiles: TP <= 2 (second-level accumulator)
 bool conv_tap_image_aligned(int variant) { return variant == 9 || variant == 11 || variant == 12; }
-bool conv_tap_stride2(int variant) { return variant == 10 || variant == 11; }
+bool conv_tap_stride2(int variant) { return variant == 10 || variant == 11 || variant == 13; }
 bool conv_tap_splitk_ok(int variant) { return variant == 3; }      // the 128 x 128 tile has the (two-pass) split-K instantiation
 bool conv_tap_pair_ok(int variant, bool f32) { return variant == 3 || ((variant == 0 || variant == 12) && !f32); }   // in-launch pair split: also the fp16 128 x 256 and image-aligned 128 x 192 tiles
 bool conv_tap_is2d(int variant) { return variant == 4 || variant == 5 || variant == 7 || variant == 8; }
@@ -766,7 +769,8 @@ bool conv_tap_fits(int variant, int W) {
     X(9, 2, 4, 4, 6, 27, 2, 1) \
     X(10, 2, 4, 4, 4, 21, 4, 4) \
     X(11, 2, 4, 4, 6, 26, 2, 4) \
-    X(12, 2, 4, 4, 3, 14, 4, 1)
+    X(12, 2, 4, 4, 3, 14, 4, 1) \
+    X(13, 2, 4, 4, 4, 26, 4, 4)
 
 const char *conv_tap_symbol(int variant, bool f32, bool fast) {
     switch (variant) {
@@ -821,11 +825,11 @@ hipError_t launch_conv_tap(const ConvParams &p0, int variant, hipStream_t s) {
     ConvParams p = p0;
     static const bool no_fast_epi = getenv("YOLO_NO_FAST_EPI") != nullptr;        // A/B switch, read once (same results either way)
     // (variant 10, the two-per-CU stride-2 tile: its lean instantiation spills 13 registers at the 128-register limit; the generic one does not)
-    p.fast_epi = (!no_fast_epi || p.fuse2) && conv_fast_epilogue_ok(p) && variant != 10 ? 1 : 0;      // (the fused pair exists in the lean form only)
+    p.fast_epi = (!no_fast_epi || p.fuse2) && conv_fast_epilogue_ok(p) && variant != 10 && (variant != 13 || p.fuse2) ? 1 : 0;      // (the fused pair exists in the lean form only)
     const bool s2 = conv_tap_stride2(variant);
     if (p.ksize != 3 || p.stride != (s2 ? 2 : 1) || p.pad != 1 || (p.cin_chunks & 3) || !conv_tap_fits(variant, p.W) || (p.f32 && !conv_tap_f32_ok(variant)))
         return hipErrorInvalidValue;
-    if (s2 ? ((p.H & 1) || (p.W & 1) || p.Ho * 2 != p.H || p.Wo * 2 != p.W || p.f32 || p.ksplit > 1 || p.fuse2 || p.outmode == OUT_POOL2 || p.qW != p.Wo + 1)
+    if (s2 ? ((p.H & 1) || (p.W & 1) || p.Ho * 2 != p.H || p.Wo * 2 != p.W || p.f32 || p.ksplit > 1 || (p.fuse2 && variant != 13) || p.outmode == OUT_POOL2 || p.qW != p.Wo + 1)
            : (p.Ho != p.H || p.Wo != p.W))
         return hipErrorInvalidValue;
     if (conv_tap_image_aligned(variant) ? (p.q_stride != p.qHW || p.Ho * (p.Wo + 1) > kTapNB[variant]) : (!conv_tap_is2d(variant) && p.q_stride != kTapNB[variant]))
@@ -858,9 +862,11 @@ hipError_t launch_conv_tap(const ConvParams &p0, int variant, hipStream_t s) {
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
-    if (p.fuse2) {          // back-to-back 1x1: the 2-D 128 x 256 tile with the lean epilogue
-        if (variant != 4 || !p.fast_epi || !p.has_res || p.n_tiles_n != 1 || p.Cout != 128 || !p.w2 || !p.b2 || !p.out2 || !p.out2_bytes) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((conv3x3_tap_kernel<false, 2, 4, 4, 4, 27, 4, 2, false, true, true>), grid, dim3(512), 0, s, p);
+    if (p.fuse2) {          // back-to-back 1x1: the 2-D 128 x 256 tile (residual block's 3x3) or the wide stride-2 tile (no residual), lean epilogue
+        if ((variant != 4 && variant != 13) || !p.fast_epi || (variant == 4) != (p.has_res != 0) || p.n_tiles_n != 1 || p.Cout != 128 || !p.w2 || !p.b2 || !p.out2 || !p.out2_bytes)
+            return hipErrorInvalidValue;
+        if (variant == 4) hipLaunchKernelGGL((conv3x3_tap_kernel<false, 2, 4, 4, 4, 27, 4, 2, false, true, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv3x3_tap_kernel<false, 2, 4, 4, 4, 26, 4, 4, false, true, true>), grid, dim3(512), 0, s, p);
         return hipGetLastError();
     }
     switch (variant) {

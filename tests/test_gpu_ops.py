@@ -438,7 +438,7 @@ def test_every_dma_tile_config(tile):
     assert "conv_igemm_dma" in names
 
 
-@pytest.mark.parametrize("case", ["residual_block_3x3", "stride2_into_stage", "default_rules_152"])
+@pytest.mark.parametrize("case", ["residual_block_3x3", "stride2_into_stage", "stride2_into_stage_tap", "default_rules_152"])
 def test_back_to_back_1x1_fusion(case, monkeypatch):
     """conv_common.h: conv_epilogue_fused_1x1 -- the 1x1 128 -> 64 conv behind a conv whose workgroups hold all 128 couts of their 256
     positions is computed by that launch (second MFMA pass over the epilogue's fp16 values through LDS), no launch of its own:
@@ -446,8 +446,9 @@ def test_back_to_back_1x1_fusion(case, monkeypatch):
     (partial tiles in both directions, several images) and the stride-2 conv 64 -> 128 into the stage on the LDS-DMA tile (M tail).
     Against the oracle, against the unfused plan of the same graph (YOLO_NO_FUSE2), and -- third case -- at the size where the
     default tile rules pick the fusing tile by themselves."""
-    if case == "stride2_into_stage":
-        B, H, W, tile = 3, 44, 58, 6
+    if case.startswith("stride2_into_stage"):
+        # LDS-DMA tile 6 (what the rules pick) and the parity-plane tap tile 23 (round 4: same fusion, no faster, forced here)
+        B, H, W, tile = (3, 44, 58, 6) if case == "stride2_into_stage" else (3, 44, 58, 23)
         g = new_graph(H, W, 64)
         g.append(PL.conv2d_bn_act(g[-1].out, 128, 3, 2))            # 1: the host (no residual)
         g.append(PL.conv2d_bn_act(g[-1].out, 64, 1, 1))             # 2: computed by 1
@@ -473,6 +474,7 @@ def test_back_to_back_1x1_fusion(case, monkeypatch):
     host = next(i for i, n in enumerate(names) if "+1x1" in n)
     assert "fused into the conv in front" in names[host + 1] and syms[host + 1] == ""
     assert ("conv_igemm_dma_kernel<2, 4, 4, 4, 3, 4, 4, true, 0>" if case == "stride2_into_stage" else
+            "conv3x3_tap_kernel<false, 2, 4, 4, 4, 26, 4, 4, false, true, true>" if "stride2" in case else
             "conv3x3_tap_kernel<false, 2, 4, 4, 4, 27, 4, 2, false, true, true>") in syms[host], syms[host]
     fused = eng.forward(x).cpu().numpy()
     assert np.array_equal(fused, eng.forward(x).cpu().numpy())
