@@ -307,7 +307,10 @@ int choose_ksplit(const Kernel &k, const ConvParams &p, int tile, size_t slab_by
     const size_t wbytes = (size_t)p.Cout * (size_t)p.taps * (size_t)p.cin_chunks * 16;
     // (1x1 layers: up to 24 MB -- tiny-YOLOv2's head 1024 -> 125 at 13x13, batch 64, is 85 workgroups walking K = 1024 alone: 85 us whole,
     // 53 us as four splits with 22 MB of partial sums)
-    const size_t small_cap = (size_t)(p.taps == 1 ? 24 : 8) << 20;
+    // 3x3: 8 MB; 16 MB where a split still walks a long K loop -- float32 (MFMA 16x slower: YOLOv2-416 b1 104 x 104 64 -> 128 43 -> 33 us,
+    // 52 x 52 and 26 x 26 layers 40 -> 33 us, step 0.815 -> 0.757 ms) or >= 8 channel slices (YOLOv3-608 b1 38 x 38: 2 -> 4 splits, 19.6 -> 18 us);
+    // a short-K fp16 layer loses with it (76 x 76 128 -> 256 at batch 1: 15.7 -> 18.8 us)
+    const size_t small_cap = (size_t)(p.taps == 1 ? 24 : (p.f32 || units >= 8) ? 16 : 8) << 20;
     while (ks >= 2 && ((size_t)ks * (size_t)p.M * cout_pad * 4 > slab_bytes || (size_t)ks * (size_t)p.M * cout_pad * 4 > (2 * wbytes > small_cap ? 2 * wbytes : small_cap))) --ks;
     if (ks < 2) return 1;
     ku = (int)((units + ks - 1) / ks);
@@ -330,11 +333,23 @@ ConvPick pick_conv(const yolo_net *net, const Kernel &k, const ConvParams &p, in
         if ((tile == 20 || tile == 21) && !conv_tile_valid(net, k, tile)) tile = conv_tile_valid(net, k, 20) ? 20 : conv_tile_valid(net, k, 5) ? 5 : 0;
         if (tile == 23 && !conv_tile_valid(net, k, 23)) tile = conv_tile_valid(net, k, 6) ? 6 : 0;
     }
+    // A launch for the in-launch pair on a WIDE tile (64-128 tiles of 128 x 256, or of the image-aligned 128 x 192: half the weight
+    // bytes per flop of the 128 x 128 tile) is not split any other way.
+    static const bool no_pair_w = getenv("YOLO_NO_PAIR_SPLIT") != nullptr;
+    bool wide_pair = false;
+    if (tile > 0 && dma_cfg_is_tap(tile) && !no_pair_w && tile_req <= 0 && !p.f32 && (p.cin_chunks >> 2) >= 8 && p.HoWo > 0) {
+        const long long mq = (long long)(p.M / p.HoWo) * (p.H + 1) * (p.W + 1);
+        const long long ct = (p.Cout + 127) / 128;
+        const long long b8 = (mq + 255) / 256 * ct, b22 = (long long)(p.M / p.HoWo) * ct;
+        wide_pair = (conv_tile_valid(net, k, 22) && b22 >= 64 && b22 <= 128 && (size_t)b22 * 2 * 98304 <= slab_bytes) ||
+                    (conv_tile_valid(net, k, 8) && b8 >= 64 && b8 <= 128 && (size_t)b8 * 2 * 131072 <= slab_bytes);
+    }
     int ku = 0;
-    int ks = choose_ksplit(k, p, tile, slab_bytes, ku);
+    int ks = wide_pair ? 1 : choose_ksplit(k, p, tile, slab_bytes, ku);
     // a 3x3/1 layer small enough for split-K runs it on the 128 x 128 tap tile (the one with the split-K instantiation), whatever
     // tile the cost model would pick for the whole-K launch
-    if (ks <= 1 && tile > 0 && dma_cfg_is_tap(tile) && tile != 11 && conv_tile_valid(net, k, 11)) {
+    // (an explicitly requested tile -- force_tile, an autotune candidate -- runs as requested)
+    if (ks <= 1 && !wide_pair && tile_req <= 0 && tile > 0 && dma_cfg_is_tap(tile) && tile != 11 && conv_tile_valid(net, k, 11)) {
         int ku11 = 0;
         const int ks11 = choose_ksplit(k, p, 11, slab_bytes, ku11);
         if (ks11 > 1) { tile = 11; ks = ks11; ku = ku11; }
