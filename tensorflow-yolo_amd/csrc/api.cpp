@@ -89,6 +89,9 @@ void yolo_net_destroy(yolo_net *net) {
     if (net->e_fork) (void)hipEventDestroy(net->e_fork);
     for (hipEvent_t e : net->e_join) (void)hipEventDestroy(e);
     for (hipStream_t st : net->side) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : net->e_bfork) (void)hipEventDestroy(e);
+    for (hipEvent_t e : net->e_bjoin) (void)hipEventDestroy(e);
+    for (hipStream_t st : net->branch) (void)hipStreamDestroy(st);
     delete net;
 }
 
@@ -498,6 +501,42 @@ hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParam
     return launch_splitk_reduce(r, s);
 }
 
+// May the branch tails of this net run beside its main chain at this batch?  Yes when the plan has any and no launch of the pass splits K.
+bool branch_tails_ok(yolo_net *net, int batch) {
+    static const bool off = getenv("YOLO_NO_BRANCH_STREAM") != nullptr;       // A/B switch (same results either way)
+    if (off || net->side_chains <= 0 || net->opt.keep_all || batch <= 0 || batch > net->opt.max_batch) return false;
+    if (net->side_ok.size() != (size_t)net->opt.max_batch + 1) net->side_ok.assign((size_t)net->opt.max_batch + 1, -1);
+    signed char &memo = net->side_ok[(size_t)batch];
+    if (memo < 0) {
+        const size_t slab = net->splitk_bytes / (size_t)net->arenas / 256 * 256;
+        const size_t data_bytes = slab > kPairCounterBytes ? slab - kPairCounterBytes : 0;
+        memo = 1;
+        for (const Kernel &k : net->kernels) {
+            if (k.kind != K_CONV || k.stem >= 2) continue;
+            ConvParams p;
+            conv_shape_params(net, k, batch, p);
+            if (pick_conv(net, k, p, k.tile, data_bytes).ks > 1) { memo = 0; break; }
+        }
+    }
+    return memo == 1;
+}
+int branch_streams(yolo_net *net, int arena) {
+    if (net->branch.empty()) {
+        const size_t n = (size_t)(net->arenas > 0 ? net->arenas : 1);
+        net->branch.assign(n, nullptr);
+        net->e_bjoin.assign(n, nullptr);
+        net->e_bfork.assign(n * 4, nullptr);
+        for (size_t i = 0; i < n; ++i)
+            if (hipStreamCreateWithFlags(&net->branch[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&net->e_bjoin[i], hipEventDisableTiming) != hipSuccess)
+                return fail(YOLO_ERR_HIP, "branch tail: stream / event creation failed");
+        for (size_t i = 0; i < n * 4; ++i)
+            if (hipEventCreateWithFlags(&net->e_bfork[i], hipEventDisableTiming) != hipSuccess)
+                return fail(YOLO_ERR_HIP, "branch tail: event creation failed");
+    }
+    return (size_t)arena < net->branch.size() ? YOLO_OK : fail(YOLO_ERR_STATE, "branch tail: arena out of range");
+}
+
 int run_forward_pass(yolo_net *net, const float *in_dev, int batch, float *out_dev, hipStream_t s, hipEvent_t *ev, int img0, int arena,
                      long long *obj_rows_out) {
     Ptrs P{net, in_dev, out_dev, img0, arena};
@@ -505,9 +544,31 @@ int run_forward_pass(yolo_net *net, const float *in_dev, int batch, float *out_d
     const int epc = net->epc;
     long long obj_rows_written = 0;          // rows of the compact objectness array the head convs of this pass fill
     bool fused2_done = false;                // the previous conv launch has computed this 1x1 conv too (back-to-back fusion)
+    // branch tails (plan.cpp: side_chains) on a second stream of this part: fork by an event behind the kernel in front of the tail,
+    // one join in front of whatever follows the pass (the decode, the caller).  Not under per-kernel events, and not at a batch where
+    // any launch of the pass splits K (the split-K slab and its ticket counters are one per arena)
+    const bool use_branch = !ev && branch_tails_ok(net, batch);
+    hipStream_t const s_main = s;
+    hipStream_t s_branch = nullptr;
+    int cur_tail = 0;
+    if (use_branch) {
+        const int rc = branch_streams(net, arena);
+        if (rc) return rc;
+        s_branch = net->branch[arena];
+    }
     for (size_t ki = 0; ki < net->kernels.size(); ++ki) {
         const Kernel &k = net->kernels[ki];
         hipError_t e = hipSuccess;
+        s = s_main;
+        if (use_branch && k.side) {
+            if (k.side != cur_tail) {
+                hipEvent_t ef = net->e_bfork[(size_t)arena * 4 + (size_t)((k.side - 1) & 3)];
+                if (hipEventRecord(ef, s_main) != hipSuccess || hipStreamWaitEvent(s_branch, ef, 0) != hipSuccess)
+                    return fail(YOLO_ERR_HIP, "branch tail: fork failed");
+                cur_tail = k.side;
+            }
+            s = s_branch;
+        }
         if (ev && hipEventRecord(ev[2 * ki], s) != hipSuccess) return fail(YOLO_ERR_HIP, "hipEventRecord failed");
         switch (k.kind) {
         case K_PREP: {
@@ -610,6 +671,10 @@ int run_forward_pass(yolo_net *net, const float *in_dev, int batch, float *out_d
             return fail(YOLO_ERR_HIP, msg);
         }
         if (ev && hipEventRecord(ev[2 * ki + 1], s) != hipSuccess) return fail(YOLO_ERR_HIP, "hipEventRecord failed");
+    }
+    if (cur_tail) {
+        if (hipEventRecord(net->e_bjoin[arena], s_branch) != hipSuccess || hipStreamWaitEvent(s_main, net->e_bjoin[arena], 0) != hipSuccess)
+            return fail(YOLO_ERR_HIP, "branch tail: join failed");
     }
     *obj_rows_out = obj_rows_written;
     return YOLO_OK;

@@ -577,6 +577,37 @@ struct Planner {
         return true;
     }
 
+    // BRANCH TAILS.  YOLOv3's heads end side branches: the 3x3 512 -> 1024 + 1x1 -> 255 behind the fifth conv of the 19 x 19 branch read
+    // that conv's output and are read by nothing but the decode, while the list goes on with the route -> 1x1 -> upsample into the
+    // 38 x 38 branch (net/v3.py:60-75).  Such a run of kernels -- a head conv that is not the last kernel plus the convs in front of it
+    // whose output has that one reader -- may run on a second stream beside the kernels that follow it: the short latency-bound
+    // launches behind the fork (1x1 + upsample, 1x1 on the concat) fill the CUs the one-workgroup-per-CU 19 x 19 tile leaves half
+    // empty.  The buffers a tail touches stay alive to the end of the pass (allocate()): nothing that runs beside it is given their bytes.
+    void side_chains() {
+        std::vector<Kernel> &K = net->kernels;
+        const int n = (int)K.size();
+        auto readers = [&](int buf) { int c = 0; for (const Kernel &k : K) c += (k.in.buf == buf) + (k.has_res && k.in2.buf == buf); return c; };
+        auto writers = [&](int buf) { int c = 0; for (const Kernel &k : K) c += k.out.buf == buf; return c; };
+        int id = 0;
+        for (int h = 0; h + 1 < n && id < 4; ++h) {
+            if (K[h].kind != K_CONV || !K[h].head || K[h].side) continue;
+            int a = h;
+            while (a - 1 >= 0) {
+                const Kernel &c = K[a], &pr = K[a - 1];
+                if (pr.kind != K_CONV || pr.head || pr.stem || pr.side || pr.fuse2_next || pr.fuse2_prev || c.has_res) break;
+                if (c.in.buf < 0 || pr.out.buf != c.in.buf || readers(c.in.buf) != 1 || writers(c.in.buf) != 1) break;
+                --a;
+            }
+            if (h - a + 1 < 2) continue;        // (a head alone: nothing to hide behind)
+            ++id;
+            for (int k = a; k <= h; ++k) {
+                K[k].side = id;
+                K[k].note += " [branch tail " + std::to_string(id) + ": may run on a second stream beside the kernels behind it]";
+            }
+        }
+        net->side_chains = id;
+    }
+
     void allocate() {
         std::vector<Buffer> &B = net->buffers;
         std::vector<Kernel> &K = net->kernels;
@@ -584,7 +615,7 @@ struct Planner {
             for (const View *v : {&K[k].in, &K[k].in2, &K[k].out}) {
                 if (v->buf < 0) continue;
                 B[v->buf].first = std::min(B[v->buf].first, k);
-                B[v->buf].last = std::max(B[v->buf].last, k);
+                B[v->buf].last = std::max(B[v->buf].last, K[k].side ? (int)K.size() - 1 : k);      // (a branch tail's tensors: to the end of the pass)
             }
             // back-to-back 1x1: its output is written by the launch of the conv IN FRONT of it -- alive one kernel earlier, or it
             // could be given the bytes of a tensor that launch still reads (its own input dies there)
@@ -665,6 +696,7 @@ int plan_network(yolo_net *net, const yolo_layer_desc *layers, int n, std::strin
     P.heads();
     P.claims();
     if (!P.emit()) { err = P.err; return YOLO_ERR_PLAN; }
+    P.side_chains();
     P.allocate();
     // workspace tail: head logits for detect(), candidate lists, counters
     size_t off = roundup_sz(net->act_bytes, 4096);

@@ -324,6 +324,8 @@ struct Kernel {
     int fuse2_next = 0;        // the NEXT kernel is a 1x1 128 -> 64 conv on this conv's output that the fused instantiation of this launch
                                // can compute (conv_common.h: conv_epilogue_fused_1x1); whether it does is decided per launch (api.cpp: conv_fuse2)
     int fuse2_prev = 0;        // ... and the mark on that 1x1: skipped when the conv in front of it has computed it
+    int side = 0;              // > 0: member of branch tail `side` (plan.cpp: side_chains): a run of kernels ending in a head conv whose
+                               // results nothing else reads -- may run on a second stream beside the kernels that follow it in the list
     size_t w_off = 0, b_off = 0, w_bytes = 0;   // inside the device weight blob
     size_t w_src = 0;                           // first float of this conv in the Darknet stream
     int batch_norm = 0;
@@ -356,6 +358,10 @@ struct yolo_net {
     size_t splitk_off = 0, splitk_bytes = 0;   // float32 partial-sum slabs of the split-K convs (small feature maps at small batch)
     size_t obj_off = 0, obj_bytes = 0;     // compact objectness logits [max_batch][rows] written by the head convs for the decode
     bool obj_valid = false;                // ... and whether the last forward filled all of it
+    int side_chains = 0;                   // number of branch tails (Kernel.side ids 1..side_chains)
+    std::vector<hipStream_t> branch;       // one stream per part for the branch tails, created at first use ...
+    std::vector<hipEvent_t> e_bfork, e_bjoin;      // ... with fork events (4 per part) and one join event per part
+    std::vector<signed char> side_ok;      // per batch: may the branch tails run beside the main chain (-1 unknown; no split-K launch in the pass)
     float obj_min_logit = -__builtin_inff();      // inside yolo_net_detect: objectness logit below which a row can never be a candidate (ConvParams.obj_min)
     std::vector<hipStream_t> side;         // multi-stream forward (YOLO_STREAMS=N): internal streams + fork/join events
     hipEvent_t e_fork = nullptr;

@@ -56,6 +56,8 @@ def test_plan_yolov3_608():
     assert engine.Plan(net, dtype="fp16", max_batch=32, streams=1).workspace_bytes < 2.5e9
     # round 4: the two 1x1 128 -> 64 convs at 152 x 152 are marked for the back-to-back fusion with the conv in front of them
     assert d.count("computed by the conv in front of it") == 2
+    # ... and the 3x3 + head conv behind the 19 x 19 and the 38 x 38 branch are branch tails (a second stream beside the route into the next scale)
+    assert d.count("[branch tail 1") == 2 and d.count("[branch tail 2") == 2 and d.count("[branch tail 3") == 0
     # ... and the library's own stream rule (yolo_net_options.streams = 0): two half batches for this net from batch 16 up, fp16 only
     assert p.num_streams == 2
     assert engine.Plan(net, dtype="fp16", max_batch=16).num_streams == 2 and engine.Plan(net, dtype="fp16", max_batch=8).num_streams == 1
