@@ -1048,6 +1048,7 @@ int yolo_net_autotune(yolo_net *net, const float *in_dev, int batch, void *strea
         }
         if (rc) break;
         k.tile = best_tile;
+        net->side_ok.clear();       // (whether a pass splits K -- branch_tails_ok -- depends on the tiles)
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
