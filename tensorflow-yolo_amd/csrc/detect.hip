@@ -58,17 +58,59 @@ __global__ void __launch_bounds__(256) decode_kernel(const DecodeParams p) {
             }
             if (!live || prob < p.threshold) continue;
         } else {
-            if (!live) continue;
-            if (po < p.threshold) continue;             // p = po * pc <= po: cheap early out, same result
-            float mx = t[5];
-            for (int k = 1; k < p.n_classes; ++k) mx = fmaxf(mx, t[5 + k]);
-            float sum = 0.f;
-            for (int k = 0; k < p.n_classes; ++k) sum += expf(t[5 + k] - mx);      // base.py:175-177
-            float best = expf(t[5] - mx) / sum;
-            for (int k = 1; k < p.n_classes; ++k) {
-                const float s = expf(t[5 + k] - mx) / sum;
-                if (s > best) { best = s; cls = k; }
+            // v2.py:102-106: p = sigmoid(obj) * max softmax(cls), class = argmax (first maximum).  p <= sigmoid(obj), so only rows whose
+            // objectness alone reaches the threshold need the softmax -- and those rows of a wave are served by 16-lane groups
+            // (butterfly max / sum / argmax) instead of three serial passes over the classes on one lane while 63 idle (round 4:
+            // YOLOv2-416 b16 49 -> 16 us; the sum of the exponentials is a butterfly sum now, not a serial one: the probabilities
+            // move by an ulp -- base.py:175-177's own pairwise sum is neither; the reference's goldens hold to 2e-6 either way).
+            float best = 0.f;
+            unsigned long long todo = __ballot(live && !(po < p.threshold));
+            // four rows at a time, one per 16-lane group (80 classes = five per lane; the butterflies stay inside a group): the passing
+            // rows of a wave are a serial chain of dependent loads (the row's class logits -> max -> exp -> sum), and at a threshold of
+            // 0.5 a third of YOLOv2's rows pass on objectness alone
+            const int grp = lane >> 4, gl = lane & 15;
+            while (todo) {
+                int src[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    src[g] = todo ? __ffsll((long long)todo) - 1 : -1;
+                    if (todo) todo &= todo - 1;
+                }
+                const int mine = grp == 0 ? src[0] : grp == 1 ? src[1] : grp == 2 ? src[2] : src[3];      // the row this lane's group serves
+                const int from = mine < 0 ? lane : mine;
+                const long long srow = ((long long)__shfl((int)(row >> 32), from) << 32) | (unsigned)__shfl((int)(row & 0xffffffffLL), from);
+                const float *ts = p.logits + srow * width + 5;
+                float mx = -3.0e38f;
+                if (mine >= 0)
+                    for (int k = gl; k < p.n_classes; k += 16) mx = fmaxf(mx, ts[k]);
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+                float sum = 0.f;
+                if (mine >= 0)
+                    for (int k = gl; k < p.n_classes; k += 16) sum += expf(ts[k] - mx);
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+                float s0 = -1.f;
+                int k0 = 0x7fffffff;
+                if (mine >= 0)
+                    for (int k = gl; k < p.n_classes; k += 16) {
+                        const float sk = expf(ts[k] - mx) / sum;
+                        if (sk > s0) { s0 = sk; k0 = k; }      // ascending k per lane: strict > keeps the first maximum
+                    }
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) {
+                    const float so = __shfl_xor(s0, off);
+                    const int ko = __shfl_xor(k0, off);
+                    if (so > s0 || (so == s0 && ko < k0)) { s0 = so; k0 = ko; }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {       // each group's verdict back to the lane that owns the row
+                    const float sb = __shfl(s0, 16 * g);
+                    const int kb = __shfl(k0, 16 * g);
+                    if (lane == src[g]) { best = sb; cls = kb; }
+                }
             }
+            if (!live || po < p.threshold) continue;    // p = po * pc <= po: same result as testing p alone
             prob = po * best;                           // v2.py:106
             if (prob < p.threshold) continue;           // v2.py:107
         }
