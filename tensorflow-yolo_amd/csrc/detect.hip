@@ -25,7 +25,8 @@ __global__ void __launch_bounds__(256) decode_kernel(const DecodeParams p) {
     for (long long row0 = (long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63); row0 < p.total_rows; row0 += stride) {
         const bool live = row0 + lane < p.total_rows;
         const long long row = live ? row0 + lane : p.total_rows - 1;
-        const int b = (int)(row / p.rows);
+        // (32-bit division where the row index allows it: always, up to batch 94 000 of YOLOv3-608)
+        const int b = p.total_rows <= 0x7fffffffLL ? (int)((unsigned)row / (unsigned)p.rows) : (int)(row / p.rows);
         const int r = (int)(row - (long long)b * p.rows);
         const float *t = p.logits + row * width;
         const float po = sigmoid_f32(p.obj ? p.obj[row] : t[4]);      // compact copy written by the head convs: coalesced
@@ -34,27 +35,39 @@ __global__ void __launch_bounds__(256) decode_kernel(const DecodeParams p) {
         if (p.version == 3) {
             prob = po;                                  // v3.py:123 p = prob_obj
             // v3.py:120-121 argmax of sigmoid(cls), first max wins.  The few rows of a wave that pass the threshold
-            // (v3.py:124, p == thr is kept) are served one after the other by ALL 64 lanes (a class or two per lane +
-            // a butterfly argmax that prefers the lower index on ties) instead of 80 serial sigmoids on one lane.
+            // (v3.py:124, p == thr is kept) are served by 16-lane groups (five classes per lane + a butterfly argmax
+            // that prefers the lower index on ties) instead of 80 serial sigmoids on one lane.
             unsigned long long todo = __ballot(live && !(prob < p.threshold));
-            while (todo) {
-                const int src = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const long long srow = ((long long)__shfl((int)(row >> 32), src) << 32) | (unsigned)__shfl((int)(row & 0xffffffffLL), src);
+            const int grp3 = lane >> 4, gl3 = lane & 15;
+            while (todo) {          // four passing rows at a time, one per 16-lane group (as the v2 path below)
+                int src[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    src[g] = todo ? __ffsll((long long)todo) - 1 : -1;
+                    if (todo) todo &= todo - 1;
+                }
+                const int mine = grp3 == 0 ? src[0] : grp3 == 1 ? src[1] : grp3 == 2 ? src[2] : src[3];
+                const int from = mine < 0 ? lane : mine;
+                const long long srow = ((long long)__shfl((int)(row >> 32), from) << 32) | (unsigned)__shfl((int)(row & 0xffffffffLL), from);
                 const float *ts = p.logits + srow * width + 5;
                 float s0 = -1.f;
                 int k0 = 0x7fffffff;
-                for (int k = lane; k < p.n_classes; k += 64) {
-                    const float sk = sigmoid_f32(ts[k]);
-                    if (sk > s0) { s0 = sk; k0 = k; }  // ascending k per lane: strict > keeps the first maximum
-                }
+                if (mine >= 0)
+                    for (int k = gl3; k < p.n_classes; k += 16) {
+                        const float sk = sigmoid_f32(ts[k]);
+                        if (sk > s0) { s0 = sk; k0 = k; }  // ascending k per lane: strict > keeps the first maximum
+                    }
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
+                for (int off = 8; off > 0; off >>= 1) {
                     const float so = __shfl_xor(s0, off);
                     const int ko = __shfl_xor(k0, off);
                     if (so > s0 || (so == s0 && ko < k0)) { s0 = so; k0 = ko; }
                 }
-                if (lane == src) cls = k0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int kb = __shfl(k0, 16 * g);
+                    if (lane == src[g]) cls = kb;
+                }
             }
             if (!live || prob < p.threshold) continue;
         } else {
