@@ -160,6 +160,7 @@ int yolo_net_bind_workspace(yolo_net *net, void *ws, size_t bytes) {
     if (bytes < net->workspace_bytes) return fail(YOLO_ERR_ARG, "yolo_net_bind_workspace: workspace too small");
     if ((uintptr_t)ws % 256) return fail(YOLO_ERR_ARG, "yolo_net_bind_workspace: workspace must be 256-byte aligned");
     net->dev_ws = static_cast<unsigned char *>(ws);
+    net->cand_clean = false;        // (whatever the new workspace holds where the candidate counters live)
     net->dev_ws_bytes = bytes;
     int rc = zero_pair_counters(net);
     if (rc) return rc;
@@ -783,7 +784,7 @@ void fill_decode(const yolo_head_desc &h, DecodeParams &dp) {
 
 int run_decode_nms(const yolo_head_desc &h, const float *logits, int batch, double thr, double iou, int mode, int cap,
                    int max_boxes, unsigned char *cand, int *cand_count, yolo_box *boxes, int32_t *counts, int32_t *status,
-                   int32_t *keep_idx, hipStream_t s, unsigned char *nms_scratch = nullptr, const float *obj = nullptr) {
+                   int32_t *keep_idx, hipStream_t s, unsigned char *nms_scratch = nullptr, const float *obj = nullptr, bool *counters_clean = nullptr) {
     DecodeParams dp;
     memset(&dp, 0, sizeof dp);
     fill_decode(h, dp);
@@ -794,7 +795,11 @@ int run_decode_nms(const yolo_head_desc &h, const float *logits, int batch, doub
     dp.cand = cand;
     dp.cand_count = cand_count;
     dp.total_rows = (long long)batch * dp.rows;
-    HIP_TRY(launch_decode(dp, batch, s));
+    // counters_clean (yolo_net_detect): the counters are the net's own; the NMS kernel returns each to zero after reading it, so only the
+    // first detect -- and one behind a failed one -- needs the memset launch (4.5 us: half a percent of a batch-1 step)
+    const bool clean = counters_clean && *counters_clean;
+    if (counters_clean) *counters_clean = false;
+    HIP_TRY(launch_decode(dp, batch, s, !clean));
     NmsParams np;
     np.cand = reinterpret_cast<const Candidate *>(cand);
     np.cand_count = cand_count;
@@ -802,7 +807,9 @@ int run_decode_nms(const yolo_head_desc &h, const float *logits, int batch, doub
     np.iou_threshold = iou;
     np.boxes = boxes; np.counts = counts; np.status = status; np.keep_idx = keep_idx;
     np.scratch = nms_scratch; np.scratch_stride = nms_scratch_bytes(cap);
+    np.reset_count = counters_clean ? cand_count : nullptr;
     HIP_TRY(launch_nms(np, batch, s));
+    if (counters_clean) *counters_clean = true;
     return YOLO_OK;
 }
 
@@ -1079,7 +1086,7 @@ int yolo_net_detect(yolo_net *net, const float *in_dev, int batch, double thresh
     return run_decode_nms(net->head, logits, batch, threshold, iou_threshold, nms_mode, net->opt.cand_capacity,
                           net->opt.max_boxes, net->dev_ws + net->cand_off, reinterpret_cast<int *>(net->dev_ws + net->count_off),
                           boxes_dev, counts_dev, status_dev, nullptr, s, net->dev_ws + net->nms_off,
-                          net->obj_valid ? reinterpret_cast<const float *>(net->dev_ws + net->obj_off) : nullptr);
+                          net->obj_valid ? reinterpret_cast<const float *>(net->dev_ws + net->obj_off) : nullptr, &net->cand_clean);
 }
 
 int yolo_net_read_layer(yolo_net *net, int layer, int batch, float *host_out, size_t n) {
@@ -1170,6 +1177,7 @@ int yolo_nms_host(const double *xywh, const float *prob, const int32_t *class_id
         NmsParams np;
         np.cand = reinterpret_cast<const Candidate *>(d_c);
         np.cand_count = d_cnt;
+        np.reset_count = nullptr;
         np.cap = n; np.max_boxes = n; np.mode = nms_mode; np.iou_threshold = iou_threshold;
         np.boxes = reinterpret_cast<yolo_box *>(d_b);
         np.counts = d_cnt + 64; np.status = d_cnt + 128;

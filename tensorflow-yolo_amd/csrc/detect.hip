@@ -184,6 +184,7 @@ __global__ void __launch_bounds__(1024) nms_kernel(const NmsParams p) {
         if (tid == 0) { p.counts[b] = 0; p.status[b] = status; }
         return;
     }
+    // (every thread has read the count: the sort's first barrier lies between this store and anything that follows the kernel)
     const bool small = n <= kNmsSmall;  // the usual case: single-wave sort + suppression bit matrix + single-wave greedy pass
     unsigned char *lds = !GLOBAL ? nms_dyn_lds : small ? small_lds : p.scratch + (size_t)blockIdx.x * p.scratch_stride;
     int n2 = 2;
@@ -203,6 +204,7 @@ __global__ void __launch_bounds__(1024) nms_kernel(const NmsParams p) {
         idx[i] = (unsigned short)i;
     }
     __syncthreads();
+    if (tid == 0 && p.reset_count) p.reset_count[b] = 0;       // every thread has read the count (barrier above)
     if (small) {
         // ~40 compare-exchange stages of <= 256 comparators: one wave runs them back to back (LDS executes a wave's
         // instructions in order), everybody else waits at ONE barrier instead of taking part in forty
@@ -362,9 +364,11 @@ size_t nms_lds_bytes(int cap) {
     return a + nms_union_bytes(cap2) + cap2 * 2 + 64;   // + kept
 }
 
-hipError_t launch_decode(const DecodeParams &p, int batch, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(p.cand_count, 0, sizeof(int) * (size_t)batch, s);
-    if (e != hipSuccess) return e;
+hipError_t launch_decode(const DecodeParams &p, int batch, hipStream_t s, bool zero_counts) {
+    if (zero_counts) {      // (not needed behind a detect whose NMS returned the counters to zero: NmsParams.reset_count)
+        hipError_t e = hipMemsetAsync(p.cand_count, 0, sizeof(int) * (size_t)batch, s);
+        if (e != hipSuccess) return e;
+    }
     long long g = (p.total_rows + 255) / 256;
     if (g > 256 * 8) g = 256 * 8;
     if (g < 1) g = 1;

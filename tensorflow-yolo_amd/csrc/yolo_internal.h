@@ -253,6 +253,7 @@ struct Candidate {             // 40 bytes
 struct NmsParams {
     const Candidate *cand;
     const int *cand_count;
+    int *reset_count;          // non-null: the kernel returns cand_count[b] to zero once it has read it (the next decode needs no memset launch)
     int cap, max_boxes, mode;
     double iou_threshold;
     yolo_box *boxes;
@@ -302,7 +303,7 @@ hipError_t launch_first(const FirstParams &p, int dtype, hipStream_t s);
 hipError_t launch_stem(const StemParams &p, int batch, hipStream_t s, int max_grid = 512);     // stem.hip
 hipError_t launch_pool(const PoolParams &p, int dtype, hipStream_t s);
 hipError_t launch_eltwise(const EltParams &p, int dtype, hipStream_t s);
-hipError_t launch_decode(const DecodeParams &p, int batch, hipStream_t s);
+hipError_t launch_decode(const DecodeParams &p, int batch, hipStream_t s, bool zero_counts = true);
 hipError_t launch_nms(const NmsParams &p, int batch, hipStream_t s);
 size_t nms_lds_bytes(int cap);
 size_t nms_scratch_bytes(int cap);
@@ -358,6 +359,7 @@ struct yolo_net {
     size_t splitk_off = 0, splitk_bytes = 0;   // float32 partial-sum slabs of the split-K convs (small feature maps at small batch)
     size_t obj_off = 0, obj_bytes = 0;     // compact objectness logits [max_batch][rows] written by the head convs for the decode
     bool obj_valid = false;                // ... and whether the last forward filled all of it
+    bool cand_clean = false;               // the candidate counters are zero (the last detect's NMS returned them): no memset launch in front of the decode
     int side_chains = 0;                   // number of branch tails (Kernel.side ids 1..side_chains)
     std::vector<hipStream_t> branch;       // one stream per part for the branch tails, created at first use ...
     std::vector<hipEvent_t> e_bfork, e_bjoin;      // ... with fork events (4 per part) and one join event per part
