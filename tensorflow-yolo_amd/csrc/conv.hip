@@ -197,6 +197,163 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams p) 
     conv_epilogue<T, TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH, m0 + wn * (TP * 16), fr);
 }
 
+// ---- float32 convs on the bf16 matrix cores: every product as nine bf16 x bf16 products (opt-in experiment: YOLO_F32_EMU=1) ----------
+// An fp32 value is EXACTLY the sum of three bf16 values (8 + 8 + 8 mantissa bits, same exponent range): x = h + m + l with
+// h = bf16(x), m = bf16(x - h), l = bf16(x - h - m).  Then a b = sum over the nine (i, j) of a_i b_j, each an exact product of two
+// 8-bit mantissas accumulated in fp32 by mfma_f32_16x16x32_bf16 -- at 16x the rate of mfma_f32_16x16x4f32, i.e. 16 / 9 of the float32
+// matrix peak.  Operands are split while they are staged (global fp32 -> registers -> three bf16 planes in LDS); the small terms are
+// added first; the accumulator is flushed into a second one every 256 k as in the fp32 kernel.  Measured (tiny-YOLOv2-VOC b64, the two
+// 13 x 13 layers that are 65 % of its step): logits 2.0e-5 from the CPU oracle (native fp32 MFMA: 2.2e-5), boxes identical;
+// 1024 -> 1024 1.81 -> 1.59 ms (127 TFLOP/s against the 137 a register-fed mfma_f32_16x16x4f32 loop sustains), step 15.3 k -> 16.7 k
+// img/s.  NOT the default: every number under profiles/ and in bench.py's lines is the native float32 path.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+
+template <int WM, int WN, int TM, int TP>
+__global__ void __launch_bounds__(512) conv_igemm_emu_kernel(const ConvParams p) {
+    typedef float T;
+    static_assert(WM * WN == 8, "eight waves per workgroup, one workgroup per CU (96 KiB of LDS): two waves per SIMD, so that one wave's split + staging runs under the other's MFMAs");
+    constexpr int NA = WM * TM * 16, NB = WN * TP * 16, LA = NA / 64, LB = NB / 64, CH = 4 * TM;
+    constexpr int PA = NA * 64, PB = NB * 64;               // one bf16 plane of the weight / pixel tile: 64-byte rows (32 k)
+    constexpr int TILE_BYTES = 3 * (PA + PB);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int bid = xcd_remap(blockIdx.x, p.n_blocks);
+    const int mt = (int)fdiv((uint32_t)bid, p.dtiles_n);
+    const int nt = bid - mt * p.n_tiles_n;
+    const int n0 = nt * NA, m0 = mt * NB;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wgt), 0, p.wgt_bytes, 0x00020000);
+    const int c = tid & 7, r0 = tid >> 3;
+    uint32_t a_off[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int r = r0 + 64 * i;
+        const int ws = r / (TM * 16), R = r % (TM * 16);
+        const int tm = R >> 4, g = (R >> 2) & 3, j = R & 3;
+        a_off[i] = (uint32_t)(n0 + ws * (TM * 16) + g * CH + 4 * tm + j) * p.wrow_bytes + c * 16;
+    }
+    uint32_t b_base[LB], b_mask[LB];
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int m = m0 + r0 + 64 * i;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = (int)fdiv((uint32_t)mm, p.dHoWo);
+        const int rem = mm - n * p.HoWo;
+        const int oy = (int)fdiv((uint32_t)rem, p.dWo), ox = rem - oy * p.Wo;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        const long long e = (long long)n * p.in_img_stride + ((long long)iy0 * p.W + ix0) * p.in_ld + p.in_coff;
+        b_base[i] = (uint32_t)(e * 4) + c * 16;
+        uint32_t mask = 0;
+        if (ok)
+            for (int t = 0; t < p.taps; ++t) {
+                const int kh = p.ksize == 3 ? (t * 11) >> 5 : 0, kw = t - kh * p.ksize;
+                if ((unsigned)(iy0 + kh) < (unsigned)p.H && (unsigned)(ix0 + kw) < (unsigned)p.W) mask |= 1u << t;
+            }
+        b_mask[i] = mask;
+    }
+    // two register sets: the loads of tile kt + 2 are in flight while tile kt + 1 is split under the MFMAs of tile kt
+    uint4v ra[2][LA], rb[2][LB];
+    auto load_tile = [&](int kt, int set) {
+        const uint32_t ka = (uint32_t)kt * 128;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) ra[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_off[i] + ka, 0, 0);
+        const int tap = (int)fdiv((uint32_t)kt, p.dtpt);
+        const uint32_t koff = (uint32_t)(kt - tap * p.tiles_per_tap) * 128;
+        const int kh = p.ksize == 3 ? (tap * 11) >> 5 : 0, kw = tap - kh * p.ksize;
+        const uint32_t toff = (uint32_t)((kh * p.W + kw) * p.in_ld * 4) + koff;
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const bool ok = tap < p.taps && ((b_mask[i] >> (tap & 15)) & 1u);
+            rb[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? b_base[i] + toff : INVALID_OFF, 0, 0);
+        }
+    };
+    // four floats -> three planes of four bf16 (8 bytes each) at row r, k = 4 c .. 4 c + 3
+    auto put = [&](unsigned char *plane0, int plane_bytes, int r, const uint4v &v) {
+        float x[4];
+        __builtin_memcpy(x, &v, 16);
+        bf16x4_t h, m, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const __bf16 hh = (__bf16)x[e];
+            const float r1 = x[e] - (float)hh;
+            const __bf16 mm = (__bf16)r1;
+            const float r2 = r1 - (float)mm;
+            h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
+        }
+        unsigned char *dst = plane0 + r * 64 + c * 8;
+        *reinterpret_cast<bf16x4_t *>(dst) = h;
+        *reinterpret_cast<bf16x4_t *>(dst + plane_bytes) = m;
+        *reinterpret_cast<bf16x4_t *>(dst + 2 * plane_bytes) = l;
+    };
+    auto store_tile = [&](int buf, int set) {
+        unsigned char *A = smem + buf * TILE_BYTES, *B = A + 3 * PA;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) put(A, PA, r0 + 64 * i, ra[set][i]);
+#pragma unroll
+        for (int i = 0; i < LB; ++i) put(B, PB, r0 + 64 * i, rb[set][i]);
+    };
+    float4v acc[TM][TP], acc2[TM][TP];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) { acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f}; acc2[a][b] = float4v{0.f, 0.f, 0.f, 0.f}; }
+    const int fr = lane & 15, fq = lane >> 4;
+    auto compute = [&](int buf) {
+        const unsigned char *A = smem + buf * TILE_BYTES + (wm * TM * 16 + fr) * 64 + fq * 16;
+        const unsigned char *B = smem + buf * TILE_BYTES + 3 * PA + (wn * TP * 16 + fr) * 64 + fq * 16;
+        // the nine plane pairs, small terms first: (l,l) (m,l) (l,m) (h,l) (l,h) (m,m) (h,m) (m,h) (h,h)
+        constexpr int PI[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}, PJ[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            bf16x8_t fa[TM], fb[TP];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const bf16x8_t *>(A + PI[t] * PA + a * 16 * 64);
+#pragma unroll
+            for (int b = 0; b < TP; ++b) fb[b] = *reinterpret_cast<const bf16x8_t *>(B + PJ[t] * PB + b * 16 * 64);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TP; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+    };
+    const int kt1 = p.ktiles;
+    load_tile(0, 0);
+    store_tile(0, 0);
+    if (kt1 > 1) load_tile(1, 1);
+    __syncthreads();
+    // iteration kt: request tile kt + 2 (register set kt & 1), MFMAs of tile kt (LDS buffer kt & 1) interleaved with the split of
+    // tile kt + 1 (register set (kt + 1) & 1, requested an iteration ago) into the other LDS buffer
+    auto iter = [&](int kt, auto parc) {
+        constexpr int par = decltype(parc)::value;
+        if (kt + 2 < kt1) load_tile(kt + 2, par);
+        compute(par);
+        if (kt + 1 < kt1) store_tile(par ^ 1, par ^ 1);
+        // (tried on top, both without effect on the 1.59 ms of the 1024 -> 1024 layer: `sched_group_barrier` pairs asking for one MFMA /
+        // two vector instructions in turn -- the scheduler still emits the 72 MFMAs first --, and the nine plane pairs with one staged
+        // piece's split pinned behind each by scheduling barriers: 1.62 ms.  The split is not what the MFMAs wait for.)
+        if ((kt & 7) == 7 || kt + 1 >= kt1) flush_acc<TM, TP>(acc, acc2);
+        __syncthreads();
+    };
+    for (int kt = 0; kt < kt1; kt += 2) {
+        iter(kt, std::integral_constant<int, 0>());
+        if (kt + 1 < kt1) iter(kt + 1, std::integral_constant<int, 1>());
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) acc[a][b] = acc2[a][b];
+    if (p.out_f32 && !p.vec_out && p.outmode == OUT_NORMAL && !p.has_res) {
+        static_assert(8 * 16 * kStagePitch(TM) * 4 <= 2 * TILE_BYTES, "staging slabs must fit in the tile buffers");
+        conv_epilogue_f32_staged<TM, TP>(p, acc, n0 + wm * (TM * 16), m0 + wn * (TP * 16), lane,
+                                         reinterpret_cast<float *>(smem) + wave * 16 * kStagePitch(TM));
+        return;
+    }
+    conv_epilogue<T, TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH, m0 + wn * (TP * 16), fr);
+}
+
 template <bool F32, bool PC>
 static hipError_t launch_cfg(const ConvParams &p0, int cfg, hipStream_t s) {
     ConvParams p = p0;
@@ -214,6 +371,11 @@ static hipError_t launch_cfg(const ConvParams &p0, int cfg, hipStream_t s) {
     conv_set_divisors(p, p.tiles_per_tap);
     if (p.ksplit > 1 && (!p.part || p.kunits < 1 || (long long)p.ksplit * p.kunits < p.ktiles)) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks, (unsigned)(p.ksplit > 1 ? p.ksplit : 1)), block(256);
+    static const bool emu = getenv("YOLO_F32_EMU") != nullptr;       // experiment: float32 products as nine bf16 products (see above)
+    if (F32 && !PC && emu && cfg == CFG_N128 && p.ksplit <= 1) {
+        hipLaunchKernelGGL((conv_igemm_emu_kernel<2, 4, 4, 2>), grid, dim3(512), 0, s, p);
+        return hipGetLastError();
+    }
     switch (cfg) {
     case CFG_N128: hipLaunchKernelGGL((conv_igemm_kernel<F32, 2, 2, 4, 4, PC>), grid, block, 0, s, p); break;
     case CFG_N64: hipLaunchKernelGGL((conv_igemm_kernel<F32, 1, 4, 4, 4, PC>), grid, block, 0, s, p); break;

@@ -521,6 +521,37 @@ def test_in_launch_pair_split_k(dtype, shape):
     assert rel_err(a, whole) <= (2e-3 if dtype == "fp16" else 2e-6)        # same products, K summed in two halves
 
 
+def test_float32_products_as_nine_bf16_products_opt_in():
+    """conv.hip: conv_igemm_emu_kernel (YOLO_F32_EMU=1, not the default): a float32 conv on the bf16 matrix cores -- every operand
+    split exactly into three bf16 values while it is staged, every product as nine bf16 x bf16 MFMA terms accumulated in fp32, small
+    terms first, two-level accumulation every 256 k.  In a process of its own (the library reads the switch once): 13 x 13 maps with
+    K = 4608 and 9216 (the tiny-YOLOv2 layers it was measured on), a 1x1, a stride-2 3x3 and a residual, at the batch where the 4-wave
+    kernel runs whole K; every layer against the oracle at the float32 tolerance of every other test."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import test_gpu_ops as T
+from tensorflow_yolo_amd.net import layers as PL, synth
+g = T.new_graph(13, 13, 512)
+g.append(PL.conv2d_bn_act(g[-1].out, 1024, 3, 1))
+g.append(PL.conv2d_bn_act(g[-1].out, 256, 1, 1))
+g.append(PL.conv2d_bn_act(g[-1].out, 1024, 3, 1))
+g.append(PL.shortcut(g[-1].out, g[1].out))
+g.append(PL.conv2d_bn_act(g[-1].out, 512, 3, 2))
+g.append(PL.max_pool2d(g[-1].out, 2, stride=1))
+x = synth.synthetic_input(40, 13, 13, 512, seed=91)
+T.check_graph(g, x, "fp32", seed=17, read=(1, 4, 5), tile=0)      # tile 0 = the 4-wave kernel (whole K at this batch)
+print("EMU OK")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, YOLO_F32_EMU="1", AMD_LOG_LEVEL="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "EMU OK" in out.stdout, out.stdout[-2000:]
+
+
 @pytest.mark.parametrize("dtype", ["fp16", "fp32"])
 @pytest.mark.parametrize("batch", [1, 2])
 def test_split_k_small_maps(dtype, batch):
