@@ -1119,7 +1119,7 @@ size_t yolo_decode_scratch_bytes(const yolo_head_desc *head, int batch, int cand
     (void)head;
     if (batch <= 0) return 0;
     if (cand_capacity <= 0) cand_capacity = 4096;
-    return ((sizeof(Candidate) * (size_t)cand_capacity * batch + 255) & ~(size_t)255) + ((sizeof(int) * (size_t)batch + 255) & ~(size_t)255) +
+    return ((sizeof(Candidate) * (size_t)cand_capacity * batch + 255) & ~(size_t)255) + ((sizeof(int) * (size_t)batch * kCandCountStride + 255) & ~(size_t)255) +
            nms_scratch_bytes(cand_capacity) * (size_t)batch;
 }
 
@@ -1137,7 +1137,7 @@ int yolo_decode_nms(const yolo_head_desc *head, const float *logits_dev, int bat
     if (scratch_bytes < yolo_decode_scratch_bytes(head, batch, cand_capacity)) return fail(YOLO_ERR_ARG, "yolo_decode_nms: scratch too small");
     unsigned char *cand = static_cast<unsigned char *>(scratch_dev);
     int *cnt = reinterpret_cast<int *>(cand + ((sizeof(Candidate) * (size_t)cand_capacity * batch + 255) & ~(size_t)255));
-    unsigned char *slabs = reinterpret_cast<unsigned char *>(cnt) + ((sizeof(int) * (size_t)batch + 255) & ~(size_t)255);
+    unsigned char *slabs = reinterpret_cast<unsigned char *>(cnt) + ((sizeof(int) * (size_t)batch * kCandCountStride + 255) & ~(size_t)255);
     return run_decode_nms(*head, logits_dev, batch, threshold, iou_threshold, nms_mode, cand_capacity, max_boxes, cand, cnt,
                           boxes_dev, counts_dev, status_dev, nullptr, static_cast<hipStream_t>(stream), slabs);
 }

@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) decode_kernel(const DecodeParams p) {
         c.cls = cls;
         c.scan = (unsigned)r;
         c.pad_ = 0;
-        const int slot = atomicAdd(&p.cand_count[b], 1);
+        const int slot = atomicAdd(&p.cand_count[b * kCandCountStride], 1);
         if (slot < p.cap) reinterpret_cast<Candidate *>(p.cand)[(long long)b * p.cap + slot] = c;
     }
 }
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(1024) nms_kernel(const NmsParams p) {
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     int nthr = blockDim.x;
-    int count = p.cand_count[b];
+    int count = p.cand_count[b * kCandCountStride];
     int status = 0;
     if (count > p.cap) { count = p.cap; status = 1; }
     const int n = count;
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(1024) nms_kernel(const NmsParams p) {
         idx[i] = (unsigned short)i;
     }
     __syncthreads();
-    if (tid == 0 && p.reset_count) p.reset_count[b] = 0;       // every thread has read the count (barrier above)
+    if (tid == 0 && p.reset_count) p.reset_count[b * kCandCountStride] = 0;       // every thread has read the count (barrier above)
     if (small) {
         // ~40 compare-exchange stages of <= 256 comparators: one wave runs them back to back (LDS executes a wave's
         // instructions in order), everybody else waits at ONE barrier instead of taking part in forty
@@ -366,7 +366,7 @@ size_t nms_lds_bytes(int cap) {
 
 hipError_t launch_decode(const DecodeParams &p, int batch, hipStream_t s, bool zero_counts) {
     if (zero_counts) {      // (not needed behind a detect whose NMS returned the counters to zero: NmsParams.reset_count)
-        hipError_t e = hipMemsetAsync(p.cand_count, 0, sizeof(int) * (size_t)batch, s);
+        hipError_t e = hipMemsetAsync(p.cand_count, 0, sizeof(int) * (size_t)batch * kCandCountStride, s);
         if (e != hipSuccess) return e;
     }
     long long g = (p.total_rows + 255) / 256;

@@ -705,7 +705,7 @@ int plan_network(yolo_net *net, const yolo_layer_desc *layers, int n, std::strin
     net->cand_off = off;
     off += roundup_sz(sizeof(Candidate) * (size_t)net->opt.cand_capacity * net->opt.max_batch, 4096);
     net->count_off = off;
-    off += roundup_sz(sizeof(int) * (size_t)net->opt.max_batch, 4096);
+    off += roundup_sz(sizeof(int) * (size_t)net->opt.max_batch * kCandCountStride, 4096);
     net->nms_off = off;
     off += roundup_sz(nms_scratch_bytes(net->opt.cand_capacity) * (size_t)net->opt.max_batch, 4096);
     net->obj_off = off;
