@@ -28,7 +28,7 @@ static int fail(int code, const std::string &msg) {
 namespace {
 // images one part of a full batch holds (what every launch of a forward pass sees at most)
 inline int part_batch(const yolo_net *net) { return (net->opt.max_batch + net->parts - 1) / net->parts; }
-const size_t kPairCounterBytes = 16384;            // in-launch pair split (conv_tap.hip): one int per tile, in front of the slabs
+const size_t kPairCounterBytes = 65536;            // in-launch pair / split-K (conv_tap.hip): one ticket per tile, a 128-byte line each (512 tiles), in front of the slabs
 bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile);
 size_t splitk_slab_bytes(const yolo_net *net);
 
@@ -394,7 +394,7 @@ ConvPick pick_conv(const yolo_net *net, const Kernel &k, const ConvParams &p, in
     if (ks > 1 && ks <= 8 && !pair && tile == 11 && !no_inl) {
         const long long mq = (long long)(p.M / p.HoWo) * (p.H + 1) * (p.W + 1);
         const long long nb11 = (mq + 127) / 128 * ((p.Cout + 127) / 128);
-        if (nb11 * 4 <= (long long)kPairCounterBytes && (size_t)nb11 * (size_t)ks * 65536 <= slab_bytes) pair = 1;
+        if (nb11 * 128 <= (long long)kPairCounterBytes && (size_t)nb11 * (size_t)ks * 65536 <= slab_bytes) pair = 1;
     }
     return ConvPick{tile, ks, ku, pair};
 }

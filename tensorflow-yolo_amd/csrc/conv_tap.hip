@@ -387,9 +387,11 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_kernel(const ConvParams 
         __syncthreads();                                        // ... and nobody reads the LDS rings any more
         int *const flag = reinterpret_cast<int *>(smem);
         if (tid == 0) {
-            const int t = __hip_atomic_fetch_add(p.pair_cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int *const ticket = p.pair_cnt + (size_t)blockIdx.x * kCandCountStride;      // (a 128-byte line per tile: the tickets of a launch
+            // arrive within a microsecond of each other, and 32 of them in one line queue behind one L2 channel)
+            const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (t == (int)nsplit - 1) {
-                __hip_atomic_store(p.pair_cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+                __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -842,7 +844,7 @@ hipError_t launch_conv_tap(const ConvParams &p0, int variant, hipStream_t s) {
         if (!(p.pair ? conv_tap_pair_ok(variant, p.f32 != 0) : conv_tap_splitk_ok(variant)) || !p.part || p.kunits < 1 ||
             (long long)p.ksplit * p.kunits < (p.cin_chunks >> 2))
             return hipErrorInvalidValue;
-        if (p.pair && (p.ksplit < 2 || (p.ksplit > 2 && variant != 3) || !p.pair_cnt ||
+        if (p.pair && (p.ksplit < 2 || (p.ksplit > 2 && variant != 3) || !p.pair_cnt || p.n_blocks > 512 ||        // (512 padded tickets: api.cpp kPairCounterBytes)
                        (unsigned long long)p.n_blocks * (unsigned long long)p.ksplit * 128ull * kTapNB[variant] * 4ull > p.part_bytes))
             return hipErrorInvalidValue;
         // (OCC 2 = up to 256 registers: the pair launches are <= 512 workgroups of half K on 256 CUs, and the 128 x 256 tile + the
