@@ -206,26 +206,19 @@ __global__ void __launch_bounds__(1024) nms_kernel(const NmsParams p) {
     __syncthreads();
     if (tid == 0 && p.reset_count) p.reset_count[b * kCandCountStride] = 0;       // every thread has read the count (barrier above)
     if (small) {
-        // ~40 compare-exchange stages of <= 256 comparators: one wave runs them back to back (LDS executes a wave's
-        // instructions in order), everybody else waits at ONE barrier instead of taking part in forty
-        if (tid < 64) {
-            for (int k = 2; k <= n2; k <<= 1) {
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int t = tid; t < (n2 >> 1); t += 64) {
-                        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                        const int l = i | j;
-                        const bool up = (i & k) == 0;
-                        const unsigned long long ki = key[i], kl = key[l];
-                        if ((ki > kl) == up) {
-                            key[i] = kl; key[l] = ki;
-                            const unsigned short s = idx[i]; idx[i] = idx[l]; idx[l] = s;
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
+        // <= 512 candidates: RANK sort -- the keys (prob descending, scan index ascending) are unique, so the place of candidate i in
+        // the sorted list is the number of keys below its own: every thread below n counts through the n keys (LDS broadcast reads,
+        // no exchange stages, one barrier) and drops its index at its rank.  (Round 4; was a single-wave bitonic network: 28 stages of
+        // dependent LDS round trips for 100 candidates, 45 for 512 -- most of the 28 us this kernel took for one YOLOv3-608 image.)
+        unsigned short *const sidx = reinterpret_cast<unsigned short *>(key + n2);     // behind the keys (the union region holds 29 B per entry)
+        if (tid < n) {
+            const unsigned long long mine = key[tid];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += key[j] < mine;
+            sidx[rank] = (unsigned short)tid;
         }
+        __syncthreads();
+        if (tid < n) idx[tid] = sidx[tid];
         __syncthreads();
     } else
     for (int k = 2; k <= n2; k <<= 1) {
