@@ -308,7 +308,7 @@ def test_fused_stem(shape):
     assert ("conv_stem<f16,3-32-64>" in names2) == (H % 2 == 0 and W % 2 == 0) and "3-32-64-32" not in names2, names2
 
 
-@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15, 16, 17, 18])
+@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 24])
 def test_tap_reuse_tile_configs(tile):
     """tap-reuse tiles of conv_tap.hip (3x3/1 only: patch of 1, 2, 4 and 6 channel slices, image borders inside a
     block, position tail; the other layers fall back to the default choice) forced through yolo_net_options.force_tile: K-stage counts 1, 2 (shorter than the
@@ -338,7 +338,7 @@ def test_tap_reuse_tile_configs(tile):
 
 @pytest.mark.parametrize("shape", [(2, 19, 19, 512, 256), (5, 13, 13, 128, 256), (3, 38, 38, 64, 128), (1, 76, 76, 128, 256), (2, 7, 78, 32, 128),
                                    (2, 5, 110, 64, 128), (1, 9, 152, 64, 128), (2, 33, 100, 32, 64), (1, 48, 304, 32, 64), (2, 21, 70, 32, 32)])
-@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 22])
+@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 22, 24])
 def test_tap_reuse_conv_shapes(shape, tile):
     """conv_tap.hip on the feature-map sizes of YOLOv3-608 (19, 38, 76), the widest rows its padded-linear tiles take
     (78, 110, 158 >= 152), wide maps for the 2-D tiles (partial 16x16 tiles in both directions, Cout 64) and a residual
@@ -357,8 +357,8 @@ def test_tap_reuse_conv_shapes(shape, tile):
         if dict(((11, cout > 64 and W <= 158), (13, cout == 64), (17, cout == 32)))[tile]:
             assert "tap9" in " ".join(ki.name.decode() for ki in eng32.kernel_infos())
     names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
-    max_w = {8: 78, 9: 78, 10: 110, 11: 158, 12: 1 << 20, 13: 1 << 20, 15: 22, 16: 1 << 20, 17: 1 << 20, 18: 19, 22: 13}[tile]
-    need = {8: cout > 64, 9: cout >= 256, 10: cout > 64, 11: cout > 64, 12: cout > 64, 13: cout == 64, 15: cout >= 256, 16: cout > 64, 17: cout == 32, 18: cout > 64 and H == W and W >= 18, 22: cout > 64 and H == W and W >= 12}[tile]
+    max_w = {8: 78, 9: 78, 10: 110, 11: 158, 12: 1 << 20, 13: 1 << 20, 15: 22, 16: 1 << 20, 17: 1 << 20, 18: 19, 22: 13, 24: 78}[tile]
+    need = {8: cout > 64, 9: cout >= 256, 10: cout > 64, 11: cout > 64, 12: cout > 64, 13: cout == 64, 15: cout >= 256, 16: cout > 64, 17: cout == 32, 18: cout > 64 and H == W and W >= 18, 22: cout > 64 and H == W and W >= 12, 24: cout > 64}[tile]
     if W <= max_w and need:             # else: the forced tile is not valid for this layer, the default one runs
         assert "tap9" in names, names
 
