@@ -23,8 +23,10 @@ Rank 0 prints ONE JSON line with the contract fields plus
                   run right after the timed region; the events add bubbles so they never time `value`)
   "cpu_baseline": the CPU oracle (torch-CPU restatement of the reference's TF path + NumPy decode/NMS,
                   kind "port") timed on the host cores on the same batch: forward and decode + NMS apart.
-  "one_stream":   (N = 1, when the timed engine runs the batch as parts on several streams) the same K steps on one stream,
-                  timed right before and right after the timed region.
+  "one_stream" / "two_streams": (N = 1) the batch as one pass on one stream and as two half batches on two streams, ALWAYS both: the mode
+                  `value` was timed in (`config.streams`; the library's rule + its on-device tuner decide) carries the timed region itself,
+                  the other mode the same K steps right before and right after it (A / timed / A) -- so that lines from different boxes,
+                  on which the tuner may decide differently, stay comparable.
 """
 import argparse
 import json
@@ -50,6 +52,9 @@ WORKLOADS = {
     "v3-416-b16-fp16": ("v3", 416, 16, "fp16"),
     "v2-416-b32-fp16": ("v2", 416, 32, "fp16"),
     "v2-416-b64-fp16": ("v2", 416, 64, "fp16"),
+    # the float32 plan -- the carrier of north_star's "1e-4 on logits + identical boxes" -- at the headline batches
+    "v3-608-b32-fp32": ("v3", 608, 32, "fp32"),
+    "v2-416-b16-fp32": ("v2", 416, 16, "fp32"),
 }
 PEAK = {"fp16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s, MI355X_MICROARCH.md "Chip-level parameters"
 COCO_V2 = [0.57273, 0.677385, 1.87446, 2.06253, 3.33843, 5.47434, 7.88282, 3.52778, 9.77052, 9.16828]
@@ -316,19 +321,33 @@ def main():
     # The roofline figures price a kernel by the duration of a whole-batch launch that has the chip to itself: when the timed engine
     # runs the batch as parts on several streams, a second engine of the same weights with streams = 1 serves the instrumented
     # passes (rank 0) -- and, at N = 1, one-stream comparison legs of the same K steps BEFORE and AFTER the timed region.
-    def one_stream_engine():
+    def other_engine(streams):
         m1 = type(model)()
-        m1.build(anchors, ["c%d" % i for i in range(ncls)], (size, size, 3), dtype=dtype, max_batch=batch, weights=w, streams=1,
+        m1.build(anchors, ["c%d" % i for i in range(ncls)], (size, size, 3), dtype=dtype, max_batch=batch, weights=w, streams=streams,
                  max_boxes=args.max_boxes, force_tile=args.force_tile)
         return m1.net.engine
+
+    def one_stream_engine():
+        return other_engine(1)
 
     eng1 = eng
     if world == 1 and eng.num_streams > 1:          # (N > 1: rank 0 builds it after the timed region, nothing beside the ranks' steps)
         eng1 = one_stream_engine()
+    # the OTHER way of running the batch, as comparison legs around the timed region (N = 1): one pass when `value` runs two halves, two
+    # halves (an explicit choice: half-size arenas) when `value` runs one pass -- whatever the tuner decided on this box, both numbers are
+    # in the line.  A batch of one image has no halves.
+    eng_other = None
+    if world == 1 and not args.no_one_stream_leg:
+        if eng.num_streams > 1:
+            eng_other = eng1
+        elif batch >= 2:
+            eng_other = other_engine(2)
+            if eng_other.num_streams != 2:
+                eng_other = None
     one_stream = None
-    legs = world == 1 and eng1 is not eng and not args.no_one_stream_leg
+    legs = eng_other is not None
     if legs:
-        one_stream = [timed_steps(eng1, xs, args.steps, args.warmup, args.threshold, args.iou_threshold)]
+        one_stream = [timed_steps(eng_other, xs, args.steps, args.warmup, args.threshold, args.iou_threshold)]
 
     def step(i):
         # forward + decode + NMS of this rank's images (one C call) and, for N > 1, the path's only exchange: ONE all-gather
@@ -341,7 +360,7 @@ def main():
     if st.any() and not os.environ.get("YOLO_BENCH_WRONG_RESULTS_OK"):      # (tools/ timing experiments with intentionally wrong kernels only)
         raise RuntimeError("candidate / box-record capacity exceeded during the benchmark: result would not match the reference")
     if legs:
-        one_stream.append(timed_steps(eng1, xs, args.steps, 0, args.threshold, args.iou_threshold))
+        one_stream.append(timed_steps(eng_other, xs, args.steps, 0, args.threshold, args.iou_threshold))
 
     out = None
     if rank == 0:
@@ -417,12 +436,18 @@ def main():
             "roofline": roof,
             "forward_frac_of_mfma_peak": round(eng.flops_per_image * total_images / elapsed / 1e12 / (PEAK[dtype] * world), 4),
         })
+        if world == 1:
+            mine = "one_stream" if eng.num_streams == 1 else "two_streams"
+            out[mine] = {"streams": int(eng.num_streams), "value": out["value"], "unit": "images/sec", "ms_per_step": out["ms_per_step"],
+                         "role": "the timed region (`value`)"}
         if legs:
             dt1 = 0.5 * (one_stream[0] + one_stream[1])
-            out["one_stream"] = {"streams": 1, "value": round(args.steps * batch / dt1, 2), "unit": "images/sec", "ms_per_step": round(dt1 / args.steps * 1e3, 4),
-                                 "ms_per_step_before_after": [round(one_stream[0] / args.steps * 1e3, 4), round(one_stream[1] / args.steps * 1e3, 4)],
-                                 "note": "same build, weights, inputs and K steps on ONE stream, timed right before and right after the timed "
-                                         "region (A / timed / A); `value` above is the %d-stream run" % eng.num_streams}
+            other = "two_streams" if eng.num_streams == 1 else "one_stream"
+            out[other] = {"streams": int(eng_other.num_streams), "value": round(args.steps * batch / dt1, 2), "unit": "images/sec",
+                          "ms_per_step": round(dt1 / args.steps * 1e3, 4),
+                          "ms_per_step_before_after": [round(one_stream[0] / args.steps * 1e3, 4), round(one_stream[1] / args.steps * 1e3, 4)],
+                          "role": "comparison legs: same build, weights, inputs and K steps, timed right before and right after the timed "
+                                  "region (A / timed / A); `value` above is the %d-stream run" % eng.num_streams}
         out["cpu_baseline"] = out["parity"] = None
         # the CPU baseline is timed on rank 0 at N = 1 only (bench contract); the parity check (rank 0's TIMED engine, every image of
         # its first batch, outside the timed region, before the process group goes away) runs at every N

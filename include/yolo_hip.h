@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define YOLO_HIP_ABI_VERSION 4      /* 2: yolo_kernel_info.symbol; 3: yolo_net_num_streams, streams = 0 is the library's rule; 4: yolo_net_tune_streams */
+#define YOLO_HIP_ABI_VERSION 5      /* 2: yolo_kernel_info.symbol; 3: yolo_net_num_streams, streams = 0 is the library's rule; 4: yolo_net_tune_streams; 5: yolo_net_set_streams */
 
 enum yolo_status {
     YOLO_OK = 0,
@@ -96,7 +96,10 @@ typedef struct yolo_net_options {
     int32_t force_tile;     /* 0: per-layer tile choice (cost model / autotune); t + 1: run conv tile id t on every
                              * conv layer that accepts it (0 = 4-wave kernel, 1-7 and 14 LDS-DMA tiles, 8-13 and 15-17
                              * tap-reuse tiles): test and tuning hook, any value gives the same results up to summation order   */
-    int32_t reserved[1];
+    int32_t guard_bytes;    /* test hook (guard-band canaries): this many extra, never-used bytes behind every planned activation
+                             * tensor (rounded into the tensor's 4 KiB-aligned region); with keep_all = 1 no two tensors share bytes, so a
+                             * pattern-filled workspace shows any kernel that writes outside its tensor (yolo_net_workspace_regions);
+                             * 0 in production                                                                                */
 } yolo_net_options;
 
 /* Result record; field names follow net/base.py:257-272 BoundingBox. */
@@ -141,6 +144,20 @@ int yolo_net_num_streams(const yolo_net *net);      /* parts / HIP streams a ful
  * build gains 3-4 % from two halves on one MI355X and loses 1-2 % on another (power-limited clocks differ from board to board).
  * No-op for nets whose streams were given explicitly or whose rule says one.  The Python engine calls it at its first full batch. */
 int yolo_net_tune_streams(yolo_net *net, const float *in_dev, int batch, void *stream);
+/* The same choice made by the caller instead of a measurement: 1 = one pass, 2 = two halves, for a net whose streams = 0 rule planned both
+ * (else only the value it already runs with is accepted: YOLO_ERR_STATE otherwise).  For processes that must all run the SAME plan -- the ranks
+ * of a sharded batch (net/dist.py broadcasts rank 0's measurement: fp16 sums of one pass and of two halves differ in order, and the step time of
+ * the job is the slowest rank's).  Not a reference call site: net/yolo.py:65-67 is one process, one session. */
+int yolo_net_set_streams(yolo_net *net, int parts);
+/* Diagnostic (ABI 5; tests/test_gpu_ops.py::test_no_kernel_writes_outside_its_tensor): the regions of the workspace the plan laid out -- every
+ * activation tensor of every arena, the head logits of detect(), candidate lists, counters, NMS scratch, the compact objectness array, the
+ * split-K slabs.  Bytes [offset, offset + used_bytes) are the region's payload; [offset + used_bytes, offset + region_bytes) belong to it but are
+ * never written by any kernel.  Fills at most `cap` records, returns the number of regions.  No reference call site (net/yolo.py holds no buffers). */
+typedef struct yolo_ws_region {
+    char name[32];
+    uint64_t offset, used_bytes, region_bytes;
+} yolo_ws_region;
+int yolo_net_workspace_regions(const yolo_net *net, yolo_ws_region *out, int cap);
 /* human-readable plan (kernels, fusions, buffers); returns bytes needed incl. NUL */
 size_t yolo_net_describe(const yolo_net *net, char *buf, size_t cap);
 

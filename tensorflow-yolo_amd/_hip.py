@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # enum yolo_op
 OP_INPUT, OP_CONV, OP_MAXPOOL, OP_ROUTE, OP_REORG, OP_SHORTCUT, OP_UPSAMPLE, OP_YOLO, OP_DETECTION = range(9)
@@ -31,7 +31,7 @@ class LayerDesc(C.Structure):
 
 class NetOptions(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("max_batch", C.c_int32), ("keep_all", C.c_int32),
-                ("cand_capacity", C.c_int32), ("max_boxes", C.c_int32), ("streams", C.c_int32), ("force_tile", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("cand_capacity", C.c_int32), ("max_boxes", C.c_int32), ("streams", C.c_int32), ("force_tile", C.c_int32), ("guard_bytes", C.c_int32)]
 
 
 class Box(C.Structure):
@@ -43,6 +43,10 @@ class HeadDesc(C.Structure):
     _fields_ = [("version", C.c_int32), ("n_classes", C.c_int32), ("n_scales", C.c_int32),
                 ("h", C.c_int32 * MAX_SCALES), ("w", C.c_int32 * MAX_SCALES), ("n_anchors", C.c_int32 * MAX_SCALES),
                 ("anchors", (C.c_double * (2 * MAX_ANCHORS)) * MAX_SCALES)]
+
+
+class WsRegion(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("offset", C.c_uint64), ("used_bytes", C.c_uint64), ("region_bytes", C.c_uint64)]
 
 
 class KernelInfo(C.Structure):
@@ -75,6 +79,8 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "yolo_net_autotune": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "yolo_net_tune_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "yolo_net_set_streams": (C.c_int, [C.c_void_p, C.c_int]),
+    "yolo_net_workspace_regions": (C.c_int, [C.c_void_p, C.POINTER(WsRegion), C.c_int]),
     "yolo_net_kernel_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(KernelInfo)]),
     "yolo_net_forward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "yolo_net_read_layer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),

@@ -130,6 +130,33 @@ int yolo_net_set_head(yolo_net *net, const yolo_head_desc *head) {
     return YOLO_OK;
 }
 
+int yolo_net_workspace_regions(const yolo_net *net, yolo_ws_region *out, int cap) {
+    if (!net) return 0;
+    int n = 0;
+    auto add = [&](const std::string &name, size_t off, size_t used, size_t region) {
+        if (out && n < cap) {
+            memset(&out[n], 0, sizeof out[n]);
+            snprintf(out[n].name, sizeof out[n].name, "%s", name.c_str());
+            out[n].offset = off; out[n].used_bytes = used; out[n].region_bytes = region;
+        }
+        ++n;
+    };
+    for (int a = 0; a < net->arenas; ++a)
+        for (size_t b = 0; b < net->buffers.size(); ++b) {
+            const Buffer &B = net->buffers[b];
+            if (!B.bytes) continue;
+            add("tensor " + std::to_string(b) + " arena " + std::to_string(a), (size_t)a * net->arena_bytes + B.offset, B.used, B.bytes);
+        }
+    const size_t mb = (size_t)net->opt.max_batch;
+    add("head logits", net->logits_off, net->out_count * 4 * mb, net->cand_off - net->logits_off);
+    add("candidates", net->cand_off, sizeof(Candidate) * (size_t)net->opt.cand_capacity * mb, net->count_off - net->cand_off);
+    add("candidate counters", net->count_off, sizeof(int) * mb * kCandCountStride, net->nms_off - net->count_off);
+    add("nms scratch", net->nms_off, nms_scratch_bytes(net->opt.cand_capacity) * mb, net->obj_off - net->nms_off);
+    add("objectness", net->obj_off, net->obj_bytes, net->splitk_off - net->obj_off);
+    if (net->splitk_bytes) add("split-K tickets + slabs", net->splitk_off, net->splitk_bytes, net->splitk_bytes);
+    return n;
+}
+
 size_t yolo_net_describe(const yolo_net *net, char *buf, size_t cap) {
     if (!net) return 0;
     std::string s = describe(net);
@@ -160,7 +187,7 @@ int yolo_net_bind_workspace(yolo_net *net, void *ws, size_t bytes) {
     if (bytes < net->workspace_bytes) return fail(YOLO_ERR_ARG, "yolo_net_bind_workspace: workspace too small");
     if ((uintptr_t)ws % 256) return fail(YOLO_ERR_ARG, "yolo_net_bind_workspace: workspace must be 256-byte aligned");
     net->dev_ws = static_cast<unsigned char *>(ws);
-    net->cand_clean = false;        // (whatever the new workspace holds where the candidate counters live)
+    net->cand_clean = 0;        // (whatever the new workspace holds where the candidate counters live)
     net->dev_ws_bytes = bytes;
     int rc = zero_pair_counters(net);
     if (rc) return rc;
@@ -784,7 +811,7 @@ void fill_decode(const yolo_head_desc &h, DecodeParams &dp) {
 
 int run_decode_nms(const yolo_head_desc &h, const float *logits, int batch, double thr, double iou, int mode, int cap,
                    int max_boxes, unsigned char *cand, int *cand_count, yolo_box *boxes, int32_t *counts, int32_t *status,
-                   int32_t *keep_idx, hipStream_t s, unsigned char *nms_scratch = nullptr, const float *obj = nullptr, bool *counters_clean = nullptr) {
+                   int32_t *keep_idx, hipStream_t s, unsigned char *nms_scratch = nullptr, const float *obj = nullptr, int *counters_clean = nullptr) {
     DecodeParams dp;
     memset(&dp, 0, sizeof dp);
     fill_decode(h, dp);
@@ -795,11 +822,15 @@ int run_decode_nms(const yolo_head_desc &h, const float *logits, int batch, doub
     dp.cand = cand;
     dp.cand_count = cand_count;
     dp.total_rows = (long long)batch * dp.rows;
-    // counters_clean (yolo_net_detect): the counters are the net's own; the NMS kernel returns each to zero after reading it, so only the
-    // first detect -- and one behind a failed one -- needs the memset launch (4.5 us: half a percent of a batch-1 step)
-    const bool clean = counters_clean && *counters_clean;
-    if (counters_clean) *counters_clean = false;
-    HIP_TRY(launch_decode(dp, batch, s, !clean));
+    // counters_clean (yolo_net_detect): the counters are the net's own; the NMS kernel returns each counter it read to zero, so only the
+    // first detect, one behind a failed one, and one at a LARGER batch than any before it need the memset launch (4.5 us: half a
+    // percent of a batch-1 step).  *counters_clean = how many counters, from the first, are known to be zero: the memset and the NMS
+    // reset cover the current call's `batch` counters only (a detect of 1 image followed by one of 32 found counters 1..31 as the
+    // caller's workspace held them -- uninitialised memory for a C-ABI caller: ADVICE r4).
+    const int clean_n = counters_clean ? *counters_clean : 0;
+    const bool need_clear = batch > clean_n;
+    if (counters_clean) *counters_clean = 0;
+    HIP_TRY(launch_decode(dp, batch, s, need_clear));
     NmsParams np;
     np.cand = reinterpret_cast<const Candidate *>(cand);
     np.cand_count = cand_count;
@@ -809,7 +840,7 @@ int run_decode_nms(const yolo_head_desc &h, const float *logits, int batch, doub
     np.scratch = nms_scratch; np.scratch_stride = nms_scratch_bytes(cap);
     np.reset_count = counters_clean ? cand_count : nullptr;
     HIP_TRY(launch_nms(np, batch, s));
-    if (counters_clean) *counters_clean = true;
+    if (counters_clean) *counters_clean = need_clear ? batch : clean_n;
     return YOLO_OK;
 }
 
@@ -993,7 +1024,10 @@ int yolo_net_tune_streams(yolo_net *net, const float *in_dev, int batch, void *s
     float *logits = reinterpret_cast<float *>(net->dev_ws + net->logits_off);
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    if (hipEventCreate(&e1) != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return fail(YOLO_ERR_HIP, "yolo_net_tune_streams: hipEventCreate failed");
+    }
     // interleaved: one pass, two halves, one pass, ... -- three forward passes per sample, the first round of each only warms up,
     // the best of the other four counts (boxes differ: the same build gains 3-4 % from two halves on one MI355X and loses 1-2 % on
     // another, so the rule's answer is re-measured where the net runs)
@@ -1016,6 +1050,17 @@ int yolo_net_tune_streams(yolo_net *net, const float *in_dev, int batch, void *s
     net->parts_tuned = rc == YOLO_OK;
     net->obj_valid = false;
     return rc;
+}
+
+int yolo_net_set_streams(yolo_net *net, int parts) {
+    if (!net) return fail(YOLO_ERR_ARG, "yolo_net_set_streams: null net");
+    if (parts == net->parts) return YOLO_OK;
+    if (!net->arena_full || parts < 1 || parts > net->arenas)
+        return fail(YOLO_ERR_STATE, "yolo_net_set_streams: this net was planned for " + std::to_string(net->parts) + " part(s) only (streams given explicitly, or the rule says one)");
+    net->parts = parts;
+    net->parts_tuned = true;
+    net->obj_valid = false;
+    return YOLO_OK;
 }
 
 int yolo_net_autotune(yolo_net *net, const float *in_dev, int batch, void *stream) {
@@ -1078,7 +1123,10 @@ int yolo_net_detect(yolo_net *net, const float *in_dev, int batch, double thresh
     // when EVERY head conv of this plan writes the compact array -- else the decode would look for objectness in rows never written.
     static const bool dense = getenv("YOLO_DENSE_LOGITS") != nullptr;       // A/B switch (same boxes either way)
     net->obj_min_logit = -INFINITY;
-    if (!dense && threshold > 0.0 && threshold < 1.0 && all_heads_write_objectness(net, in_dev, logits, batch))
+    // (thresholds within 1e-4 of 1 run dense: there the decode's float32 sigmoid saturates -- sigmoid_f32(x) rounds to 1 - 2^-23 over a range
+    // of x wider than the 0.01 margin, so rows the decode accepts would lie below the cut; at 1 - 1e-4 the margin is still ten float32
+    // rounding errors of p wide)
+    if (!dense && threshold > 0.0 && threshold < 1.0 - 1e-4 && all_heads_write_objectness(net, in_dev, logits, batch))
         net->obj_min_logit = (float)(std::log(threshold / (1.0 - threshold)) - 0.01);
     rc = run_forward(net, in_dev, batch, logits, s);
     net->obj_min_logit = -INFINITY;

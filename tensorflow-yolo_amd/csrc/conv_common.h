@@ -516,7 +516,8 @@ constexpr int kStagePitch(int TM) { return 16 * TM + 4; }       // floats per pi
 // columns of a failed anchor.  yolo_net_forward (dense logits for the caller) never sets obj_min.
 constexpr int kStageFlagAnchors = 8;
 
-template <int TM, int TP, int PADQ = 0, bool BIAS_IN_ACC = false>
+// NBW: pixels of the WORKGROUP's tile (rows of `flags`)
+template <int TM, int TP, int PADQ = 0, bool BIAS_IN_ACC = false, int NBW = 0>
 __device__ __forceinline__ void conv_epilogue_f32_staged(const ConvParams &p, float4v (&acc)[TM][TP], int cbase_wave, int m_wave,
                                                          int lane, float *slab, float *flags = nullptr, int pix0 = 0) {
     constexpr int CH = 4 * TM;
@@ -559,11 +560,20 @@ __device__ __forceinline__ void conv_epilogue_f32_staged(const ConvParams &p, fl
         obj_a[h] = (p.obj_out && lane + 64 * h < 4 * CH && cg < p.Cout && cg - a * p.obj_width == 4) ? a : -1;
         col_a[h] = a < kStageFlagAnchors ? a : kStageFlagAnchors - 1;
     }
-    const bool sparse = flags != nullptr && p.obj_out != nullptr && p.obj_min > -3.0e38f && p.obj_na <= kStageFlagAnchors &&
+    const bool sparse = NBW > 0 && flags != nullptr && p.obj_out != nullptr && p.obj_min > -3.0e38f && p.obj_na <= kStageFlagAnchors &&
                         p.obj_width > CH;      // kernel-uniform; (5 + classes > CH: a lane's CH couts hold at most ONE objectness channel)
     float objv[TP];             // the objectness logits this lane holds (pixel fr of every fragment), anchor obj_an; -1: none
     int obj_an = -1;
     if (sparse) {
+        // The verdict of an anchor exists only in the workgroup whose cout tile holds that anchor's objectness channel (255 or 425 head
+        // channels span two to four 128-cout tiles: anchor 1's channel 89 sits in tile 0, its class columns 128..169 in tile 1).  Every
+        // flag therefore starts as "write the row": the columns of an anchor this workgroup cannot judge are always stored, and only the
+        // lanes that own an objectness channel may turn a flag off.  (Round 4 read those slots uninitialised -- leftover ring bytes.)
+        {
+            const int n_flags = NBW * kStageFlagAnchors;
+            for (int i = (int)threadIdx.x; i < n_flags; i += (int)blockDim.x) flags[i] = 1.f;
+            __syncthreads();
+        }
         int r = cbase % p.obj_width, a = cbase / p.obj_width;
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
@@ -589,9 +599,13 @@ __device__ __forceinline__ void conv_epilogue_f32_staged(const ConvParams &p, fl
         if (sparse) {
             // no anchor of these 16 pixels can be a candidate (the usual case): nothing of the fragment goes to the logits, its
             // objectness logits go to the compact array straight from the lanes that hold them -- no slab, no store loop
+            // (only the anchors that own one of THIS wave's columns count: the others' rows are stored by other waves / workgroups)
             bool any = false;
-            if (lane < 16)
-                for (int a = 0; a < p.obj_na; ++a) any = any || flags[(pix0 + b * 16 + lane) * kStageFlagAnchors + a] != 0.f;
+            if (lane < 16) {
+                const int c_end = (cbase_wave + 4 * CH < p.Cout ? cbase_wave + 4 * CH : p.Cout) - 1;
+                const int a_lo = cbase_wave / p.obj_width, a_hi = c_end / p.obj_width < p.obj_na ? c_end / p.obj_width : p.obj_na - 1;
+                for (int a = a_lo; a <= a_hi; ++a) any = any || flags[(pix0 + b * 16 + lane) * kStageFlagAnchors + a] != 0.f;
+            }
             if (!__builtin_amdgcn_ballot_w64(any)) {
                 if (ok && obj_an >= 0) p.obj_out[orow + obj_an] = objv[b];
                 continue;

@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(512, OCC) conv_igemm_dma_kernel(const ConvPara
     if constexpr (EPI == 2) {      // head conv: coalesced float32 rows via LDS
         static_assert(8 * 16 * kStagePitch(TM) * 4 + NB * kStageFlagAnchors * 4 <= S * TILE_BYTES, "staging slabs + row flags must fit in the ring");
         __syncthreads();            // every wave is done reading the ring
-        conv_epilogue_f32_staged<TM, TP, 0, true>(p, acc, n0 + wm * (TM * 16), m0 + wn * (TP * 16), lane,
+        conv_epilogue_f32_staged<TM, TP, 0, true, NB>(p, acc, n0 + wm * (TM * 16), m0 + wn * (TP * 16), lane,
                                          reinterpret_cast<float *>(smem) + wave * 16 * kStagePitch(TM),
                                          reinterpret_cast<float *>(smem) + 8 * 16 * kStagePitch(TM), wn * (TP * 16));
     } else if constexpr (EPI == 1) {    // (plain fp16 output map, aligned views below 2 GiB)
@@ -281,12 +281,10 @@ static const DmaCfg kCfgs[] = {
     {128, 384, 1, 1.00f, "128x384,tap9,s2,img", 4},    // 21: conv_tap.hip variant 11: ... one whole (19 x 19) output image per tile
     {128, 192, 2, 1.00f, "128x192,tap9,img,x2", 4},    // 22: conv_tap.hip variant 12: one whole 12 x 12 / 13 x 13 image per tile (stride 1)
     {128, 256, 2, 1.00f, "128x256,tap9,s2,wide,x2", 4},   // 23: conv_tap.hip variant 13: tile 20 for output maps up to 158 wide; hosts the back-to-back 1x1
-    {128, 256, 2, 1.00f, "128x256,tap9,4w,x2", 4},        // 24: conv_tap.hip variant 14: tile 8 as four fat waves (64 couts x 128 positions each)
-    {128, 384, 1, 1.00f, "128x384,tap9", 4},              // 25: conv_tap.hip variant 15: tile 18's shape on the padded-linear grid (maps up to 40 wide)
 };
-static const int kNumCfgs = 26;
+static const int kNumCfgs = 24;
 static const int kFirstTapCfg = 8, kLastTapCfg = 13;
-static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || (cfg >= 15 && cfg <= 18) || (cfg >= 20 && cfg <= 25); }
+static inline bool is_tap_cfg(int cfg) { return (cfg >= kFirstTapCfg && cfg <= kLastTapCfg) || (cfg >= 15 && cfg <= 18) || (cfg >= 20 && cfg <= 23); }
 static inline int tap_variant(int cfg) { return cfg >= 20 ? cfg - 10 : cfg >= 15 ? cfg - 9 : cfg - kFirstTapCfg; }     // conv_tap.hip variant of a tap cfg
 bool dma_cfg_is_tap(int cfg) { return is_tap_cfg(cfg); }
 bool dma_cfg_f32_ok(int cfg) { return is_tap_cfg(cfg) && conv_tap_f32_ok(tap_variant(cfg)); }
@@ -339,8 +337,6 @@ static const TileCost kCost[] = {
     {0.90f, 0.90f, 0.90f, 18.0f},       // 21: 128x384 image-aligned stride-2 tap reuse (as tile 18)
     {0.94f, 1.32f, 0.68f, 8.5f},        // 22: 128x192 image-aligned tap reuse, two per CU (as tile 10)
     {0.0f, 0.0f, 0.0f, 0.0f},           // 23: wide stride-2 tap reuse (chosen by rule)
-    {1.20f, 1.45f, 0.76f, 7.9f},        // 24: 128x256 tap reuse, four fat waves, two per CU (as tile 8 until measured)
-    {0.90f, 0.90f, 0.90f, 18.0f},       // 25: 128x384 padded-linear tap reuse (as tile 18 until measured)
 };
 
 int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool v1_ok, int stride, int W, bool tap_only) {
@@ -391,7 +387,7 @@ int choose_dma_cfg(int M, int cout, int cin_chunks, int taps, int has_res, bool 
         const long long wg128 = (long long)((M + 127) / 128) * ((cout + 127) / 128);
         if (c == 14 && taps != 1 && !(stride == 2 && wg128 > 128 && wg128 <= 256)) continue;
         if (c == 19 && taps != 1) continue;     // (measured on 1x1 layers only)
-        if (c == 7 || c == 13 || c == 16 || c == 17 || c == 23 || c == 24 || c == 25 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
+        if (c == 7 || c == 13 || c == 16 || c == 17 || c == 23 || !dma_cfg_valid(c, cout, cin_chunks, v1_ok, ksize, stride, W)) continue;
         const DmaCfg &k = kCfgs[c];
         // tap-reuse tiles walk the padded position grid: (H+1)(W+1) positions per image (square maps assumed here)
         long long Meff = M;

@@ -27,9 +27,6 @@
 #include "conv_common.h"
 #include <type_traits>
 
-#ifndef YOLO_TAP_DPP
-#define YOLO_TAP_DPP 0
-#endif
 #ifndef YOLO_TAP_DBG        // timing experiments of tools/ (make EXTRA=-DYOLO_TAP_DBG=..): never set in the product build
 #define YOLO_TAP_DBG 0
 #endif
@@ -93,13 +90,10 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
     constexpr bool TWO_D = MODE == 2 || MODE == 3;       // MODE 3: the 2-D tiles of MODE 2 with the max-pool behind the conv taken in the epilogue
     constexpr bool S2 = MODE == 4;          // 3x3 / stride 2 over the four parity planes of the input (see run_slice_s2 below)
     constexpr int PADQ = TWO_D ? 2 : 1;
-    // WM x WN waves: eight, or FOUR "fat" waves (round 5: the same 128 x 256 block tile as 2 x 2 waves of 64 couts x 128 positions,
-    // 12 fragment reads per 32 MFMAs instead of 8 per 16 and half the barriers per MFMA; see the variant table below)
     constexpr int NW = WM * WN;
     constexpr int S = 3;                    // weight ring slots (9 taps per slice: slot = tap % 3)
     constexpr bool STAG = YOLO_TAP_STAGGER != 0 && !F32 && !SPLITK && TM % 2 == 0 && NW == 8 && MODE == 4 && OCC == 4;    // half-tap stagger of waves 4-7 (below)
     constexpr int TMH = TM / 2;
-    constexpr bool FAT = NW == 4 && !F32 && !SPLITK && MODE == 1 && TP % TM == 0;      // four fat waves: software-pipelined fragment reads (compute_fat below)
     constexpr int ROWB = 64;
     constexpr int NA = WM * TM * 16;
     constexpr int NB = WN * TP * 16;
@@ -114,7 +108,7 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
     constexpr int CH = 4 * TM;
     constexpr int A_BYTES = NA * ROWB;
     constexpr int P_BYTES = PRG * 1024;
-    static_assert(NW == 8 || NW == 4, "eight waves, or four fat ones");
+    static_assert(NW == 8, "eight waves");
     static_assert(JA_TOT % NW == 0 || JA_TOT < NW, "weight tile must split evenly over the waves (or be smaller than them)");
     static_assert(!TWO_D || PRG * 16 >= (NB / 16 + 2) * PW, "patch buffer too small for the 2-D tile");
     if constexpr (F32 && (TP > 2 || OCC >= 6)) return;     // never launched (launch_conv_tap refuses): no registers for the second accumulator
@@ -282,49 +276,6 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
             for (int b = 0; b < TP; ++b) acc[a][b] = mma_chunk<T>(fa[a], fb[b], acc[a][b]);
     };
 
-    // POSITION FRAGMENTS BY LANE SHIFT (round 5, YOLO_TAP_DPP).  The three taps of a kernel row read the SAME patch rows shifted by one position:
-    // fragment b of tap (kh, kw) is rows R + 16 b + kw .. + 15 of the patch, lane row fr <-> patch row, lane group fq <-> channel chunk.  So taps
-    // kw = 1, 2 need no LDS read at all: lane fr takes lane fr + 1's registers of the same fragment (DPP row_shl:1 inside each 16-lane row) and
-    // lane 15 takes lane 0 of the next fragment (row_ror:15 of it, kept where row_shl has no source); one extra fragment (rows R + 64 ..) is
-    // read at kw = 0 for the last one.  5 position reads per kernel row instead of 12: 17 fragment reads per three taps instead of 24, for
-    // 36 cross-lane moves per shifted tap on the vector pipe, which the K loop leaves idle.
-    constexpr bool DPPB = YOLO_TAP_DPP != 0 && !F32 && MODE == 1 && !FAT && !STAG;
-    uint4v fbs[DPPB ? TP + 1 : 1];
-    auto shift_rows = [&](const uint4v &cur, const uint4v &next) {
-        uint4v o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int t = __builtin_amdgcn_mov_dpp((int)next[e], 0x12F /* row_ror:15: every lane has a source */, 0xF, 0xF, false);
-            o[e] = (unsigned)__builtin_amdgcn_update_dpp(t, (int)cur[e], 0x101 /* row_shl:1 */, 0xF, 0xF, false);
-        }
-        return o;
-    };
-    auto compute_dpp = [&](int slot, int buf, int kh, int kw) {
-        if constexpr (DPPB) {
-            const unsigned char *A = smem + slot * A_BYTES + a_frag;
-            uint4v fa[TM];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const uint4v *>(A + a * 16 * ROWB);
-            if (kw == 0) {
-                const int R = rb + kh * p.qW;
-                const unsigned char *B = smemP + buf * P_BYTES + (R << 6) + ((fq << 4) ^ ((R & 4) << 3));
-#pragma unroll
-                for (int b = 0; b <= TP; ++b) fbs[b] = *reinterpret_cast<const uint4v *>(B + b * FROW * ROWB);
-            } else {
-#pragma unroll
-                for (int b = 0; b < TP; ++b) fbs[b] = shift_rows(fbs[b], fbs[b + 1]);
-                if (kw == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) fbs[TP][e] = (unsigned)__builtin_amdgcn_mov_dpp((int)fbs[TP][e], 0x101, 0xF, 0xF, false);     // (lane 15: never used)
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TP; ++b) acc[a][b] = mma_chunk<T>(fa[a], fbs[b], acc[a][b]);
-        }
-    };
-
     // HALF-TAP STAGGER (round 5).  All eight waves of a workgroup run the same program between the same barriers, so the two waves
     // that share a SIMD (w and w + 4) reach their fragment reads -- and the ~150-250 cycles until the first of them is back --
     // together, and nothing feeds the matrix pipe meanwhile: with the barriers removed (wrong results; profiles/r05_ablation.md)
@@ -380,54 +331,6 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
         }
     };
     const bool late = STAG && wave >= YOLO_TAP_LATE_FROM;        // wave-uniform
-
-    // FOUR FAT WAVES (variant 14).  One wave per SIMD and workgroup: nobody of the same workgroup covers a wave's wait for its fragments, so
-    // the reads are software-pipelined with the registers the wave has (256 at two waves per SIMD).  The POSITION fragments of tap t + 1
-    // are read during the MFMAs of tap t into a second register set: the patch of a slice is complete and visible long before (waited for
-    // at taps 1-2 of the slice in front), so those reads need no barrier -- and they are the last reads of a patch buffer one tap EARLIER
-    // than before, which keeps the write-after-read distance to the next patch DMA (issued behind the barrier of tap 0).  The WEIGHT
-    // fragments can only be read behind the tap's barrier (their DMA is waited for in front of it): fragment a + 1 is read while the eight
-    // MFMAs of fragment a run, so one read latency per tap is exposed instead of one per fragment.  sched_group_barrier pins that order.
-    uint4v fbq[FAT ? 2 : 1][FAT ? TP : 1];
-    auto patch_ptr = [&](int buf, int shift) {
-        if constexpr (YOLO_TAP_RECOMPUTE_ADDR != 0) asm volatile("" : "+s"(shift));     // opaque: the address is computed per tap (five vector instructions
-        // beside 32 MFMAs) instead of living in nine loop-invariant registers
-        const int R = rb + shift;
-        return smemP + buf * P_BYTES + (R << 6) + ((fq << 4) ^ ((R & 4) << 3));
-    };
-    auto compute_fat = [&](int slot, auto parc, int nbuf, int nshift) {
-        if constexpr (FAT) {
-            constexpr int PAR = decltype(parc)::value;
-            constexpr int NPF = TP / TM;        // position fragments of the next tap read per cout fragment of this one
-            const unsigned char *A = smem + slot * A_BYTES + a_frag;
-            const unsigned char *Bn = patch_ptr(nbuf, nshift);
-            uint4v fa[2];
-            fa[0] = *reinterpret_cast<const uint4v *>(A);
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                if (a + 1 < TM) fa[(a + 1) & 1] = *reinterpret_cast<const uint4v *>(A + (a + 1) * 16 * ROWB);
-#pragma unroll
-                for (int i = 0; i < NPF; ++i) fbq[PAR ^ 1][a * NPF + i] = *reinterpret_cast<const uint4v *>(Bn + (a * NPF + i) * FROW * ROWB);
-#pragma unroll
-                for (int b = 0; b < TP; ++b) acc[a][b] = mma_chunk<T>(fa[a & 1], fbq[PAR][b], acc[a][b]);
-            }
-#if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // weight fragment 0
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                if (a + 1 < TM) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // weight fragment a + 1
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-#pragma unroll
-                for (int i = 0; i < NPF; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                  // a position fragment of the next tap
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, TP - 2 - 2 * NPF, 0);
-            }
-#endif
-        }
-    };
-
     // ---- prologue: patch of slice 0, weights of taps 0 and 1 --------------------------------------
 #ifdef YOLO_EXPERIMENT
     const unsigned long long t_setup = p.trace ? wall_clock64() : 0ull;
@@ -522,25 +425,10 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
             }
             if (tap == 0 && more) issue_patch(c + 1, buf ^ 1);
             const int kh = tap / 3, kw = tap - 3 * kh;
-            if constexpr (FAT) {
-                const int tn = tap + 1 < 9 ? tap + 1 : 0, khn = tn / 3, kwn = tn - 3 * khn;
-                // (9 taps per slice: the register sets swap roles from slice to slice as well; the loop is unrolled, the branch folds)
-                if (((buf * 9 + tap) & 1) == 0) compute_fat(tap % S, std::integral_constant<int, 0>(), tap + 1 < 9 ? buf : buf ^ 1, khn * p.qW + kwn);
-                else compute_fat(tap % S, std::integral_constant<int, 1>(), tap + 1 < 9 ? buf : buf ^ 1, khn * p.qW + kwn);
-            }
-            else if constexpr (LATE) compute_late(tap % S, buf, TWO_D ? kh * PW + kw : kh * p.qW + kw);
-            else if constexpr (DPPB) compute_dpp(tap % S, buf, kh, kw);
+            if constexpr (LATE) compute_late(tap % S, buf, TWO_D ? kh * PW + kw : kh * p.qW + kw);
             else compute(tap % S, buf, TWO_D ? kh * PW + kw : kh * p.qW + kw);
         }
     };
-    if constexpr (FAT) {        // the position fragments of the very first tap: the patch is the oldest DMA in flight
-        tap_wait_vm<2 * JA>();
-        __builtin_amdgcn_s_barrier();
-        const unsigned char *B0 = patch_ptr(0, 0);
-#pragma unroll
-        for (int b = 0; b < TP; ++b) fbq[0][b] = *reinterpret_cast<const uint4v *>(B0 + b * FROW * ROWB);
-        __builtin_amdgcn_sched_barrier(0);
-    }
     auto run_all = [&](auto latec) {
         if constexpr (STAG) init_acc();
         if constexpr (decltype(latec)::value) {
@@ -957,18 +845,14 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_stream_kernel(const Conv
 // tiles x 2 K halves = 256 workgroups
 // 13 = variant 10 with a patch of 26 row groups (output maps up to 158 wide): the stride-2 conv into the 152 x 152 stage, whose
 // workgroups hold all 128 couts of 256 positions -- the one stride-2 tile with the back-to-back 1x1 instantiation (FUSE2)
-// 14 = variant 0's block tile (128 couts x 256 positions, two workgroups per CU) as FOUR waves of 64 couts x 128 positions (round 5).
-// Ablation builds of the eight-wave tile (profiles/r05_ablation.md: results wrong, timing only) priced its K loop: without the fragment reads
-// a launch is 18-22 % shorter, with 6 reads per 16 MFMAs instead of 8 7-12 % shorter, without the barriers 7-9 % -- the matrix pipe is
-// held back by the LDS -> register fragment traffic, then by the rendezvous per 16 MFMAs.  A 64 x 128 wave tile reads 12 fragments per 32
-// MFMAs (0.375 per MFMA instead of 0.5) and meets its three partners once per 32 MFMAs; 128 accumulator registers of the 256 a wave has at
-// two waves per SIMD.  Same LDS image, same DMA traffic, same workgroup count as variant 0.
-// 15 = variant 9's tile (128 couts x 384 positions, one workgroup per CU, 10 fragment reads per 24 MFMAs) on the PADDED-LINEAR grid, for maps
-// up to 40 wide: 38 x 38 at batch 32 is 127 x 4 = 508 tiles on 256 CUs = 1.98 rounds, where the 128 x 256 tile's 764 workgroups fill 512 slots 1.49 times
-static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224, 128, 256, 384, 256, 384, 192, 256, 256, 384};
-static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17, 12, 27, 27, 21, 26, 14, 26, 26, 30};
-static const int kTapVariants = 16;
-static const bool kTapF32[] = {false, false, false, true, false, true, false, false, true, false, false, false, false, false, false, false};      // float32 tiles: TP <= 2 (second-level accumulator)
+// (round 5, measured and NOT kept -- profiles/r05_ablation.md, source in commit 57e38ee: variant 0's block tile as four fat waves of 64 couts x 128
+// positions with the position fragments prefetched across the barrier, +0.5 ... +2.5 % slower; variant 9's 128 x 384 tile on the padded-linear grid
+// for 38 x 38 maps -- 508 tiles on 256 CUs -- +4.3 % slower than the 764 workgroups of variant 0; position fragments of the taps kw = 1, 2 by DPP lane
+// shifts instead of LDS reads, correct and +5 ... +9 % slower)
+static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224, 128, 256, 384, 256, 384, 192, 256};
+static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17, 12, 27, 27, 21, 26, 14, 26};
+static const int kTapVariants = 14;
+static const bool kTapF32[] = {false, false, false, true, false, true, false, false, true, false, false, false, false, false};      // float32 tiles: TP <= 2 (second-level accumulator)
 bool conv_tap_image_aligned(int variant) { return variant == 9 || variant == 11 || variant == 12; }
 bool conv_tap_stride2(int variant) { return variant == 10 || variant == 11 || variant == 13; }
 bool conv_tap_splitk_ok(int variant) { return variant == 3; }      // the 128 x 128 tile has the (two-pass) split-K instantiation
@@ -990,8 +874,6 @@ bool conv_tap_fits(int variant, int W) {
 
 // variant id, then the template arguments after F32: WM, WN, TM, TP, PRG, OCC, MODE (written with ", " so that the
 // stringified list equals the demangled symbol)
-#define YOLO_TAP_VARIANTS4(X) \
-    X(14, 2, 2, 4, 8, 26, 2, 1)
 #define YOLO_TAP_VARIANTS(X) \
     X(0, 2, 4, 4, 4, 26, 4, 1) \
     X(1, 2, 4, 8, 4, 26, 2, 1) \
@@ -1006,8 +888,7 @@ bool conv_tap_fits(int variant, int W) {
     X(10, 2, 4, 4, 4, 21, 4, 4) \
     X(11, 2, 4, 4, 6, 26, 2, 4) \
     X(12, 2, 4, 4, 3, 14, 4, 1) \
-    X(13, 2, 4, 4, 4, 26, 4, 4) \
-    X(15, 2, 4, 4, 6, 30, 2, 1)
+    X(13, 2, 4, 4, 4, 26, 4, 4)
 
 const char *conv_tap_symbol(int variant, bool f32, bool fast) {
     switch (variant) {
@@ -1015,7 +896,6 @@ const char *conv_tap_symbol(int variant, bool f32, bool fast) {
                                        : fast ? "void yolo::conv3x3_tap_kernel<false, " #__VA_ARGS__ ", false, true, false>(yolo::ConvParams)" \
                                               : "void yolo::conv3x3_tap_kernel<false, " #__VA_ARGS__ ", false, false, false>(yolo::ConvParams)";
         YOLO_TAP_VARIANTS(X)
-        YOLO_TAP_VARIANTS4(X)
 #undef X
     default: return "";
     }
@@ -1114,13 +994,6 @@ hipError_t launch_conv_tap(const ConvParams &p0, int variant, hipStream_t s) {
         else hipLaunchKernelGGL((conv3x3_tap_kernel<false, __VA_ARGS__, false>), grid, dim3(512), 0, s, p); \
         break;
         YOLO_TAP_VARIANTS(X)
-#undef X
-#define X(id, ...) case id: \
-        if (p.f32) return hipErrorInvalidValue; \
-        else if (p.fast_epi) hipLaunchKernelGGL((conv3x3_tap_kernel<false, __VA_ARGS__, false, true>), grid, dim3(256), 0, s, p); \
-        else hipLaunchKernelGGL((conv3x3_tap_kernel<false, __VA_ARGS__, false>), grid, dim3(256), 0, s, p); \
-        break;
-        YOLO_TAP_VARIANTS4(X)       // four fat waves per workgroup
 #undef X
     default: return hipErrorInvalidValue;
     }

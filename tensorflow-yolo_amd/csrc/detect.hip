@@ -214,7 +214,9 @@ __global__ void __launch_bounds__(1024) nms_kernel(const NmsParams p) {
         if (tid < n) {
             const unsigned long long mine = key[tid];
             int rank = 0;
-            for (int j = 0; j < n; ++j) rank += key[j] < mine;
+            // (ties broken by the slot index: a total order for ANY input -- yolo_net_detect's scan indices are unique, those a caller of
+            // yolo_nms_host / yolo_decode_nms passes need not be, and two equal ranks would leave a slot of sidx unwritten)
+            for (int j = 0; j < n; ++j) { const unsigned long long kj = key[j]; rank += (kj < mine) || (kj == mine && j < tid); }
             sidx[rank] = (unsigned short)tid;
         }
         __syncthreads();

@@ -648,7 +648,11 @@ struct Planner {
             net->parts = net->arenas;
         }
         const int arena_batch = net->arena_full ? net->opt.max_batch : (net->opt.max_batch + net->arenas - 1) / net->arenas;
-        for (Buffer &b : B) b.bytes = roundup_sz((size_t)b.elems_per_image * b.esize * arena_batch + 256, align);
+        const size_t guard = net->opt.guard_bytes > 0 ? (size_t)net->opt.guard_bytes : 0;      // (test hook: yolo_net_options.guard_bytes)
+        for (Buffer &b : B) {
+            b.used = (size_t)b.elems_per_image * b.esize * arena_batch;
+            b.bytes = roundup_sz(b.used + 256 + guard, align);
+        }
         size_t top = 0;
         if (net->opt.keep_all) {
             for (Buffer &b : B) { b.offset = top; top += b.bytes; }

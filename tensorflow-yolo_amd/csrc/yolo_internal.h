@@ -39,6 +39,7 @@ struct Buffer {
     int first = 1 << 30, last = -1; // kernel indices of first write / last access
     size_t offset = 0;              // bytes inside the workspace
     size_t bytes = 0;               // for max_batch
+    size_t used = 0;                // payload bytes of the region (the rest is alignment slack + yolo_net_options.guard_bytes)
     bool is_concat = false;
 };
 
@@ -364,7 +365,7 @@ struct yolo_net {
     size_t splitk_off = 0, splitk_bytes = 0;   // float32 partial-sum slabs of the split-K convs (small feature maps at small batch)
     size_t obj_off = 0, obj_bytes = 0;     // compact objectness logits [max_batch][rows] written by the head convs for the decode
     bool obj_valid = false;                // ... and whether the last forward filled all of it
-    bool cand_clean = false;               // the candidate counters are zero (the last detect's NMS returned them): no memset launch in front of the decode
+    int cand_clean = 0;                    // how many candidate counters, from the first, are known to be zero (the last detect's NMS returned them): no memset launch in front of a decode of at most that batch
     int side_chains = 0;                   // number of branch tails (Kernel.side ids 1..side_chains)
     std::vector<hipStream_t> branch;       // one stream per part for the branch tails, created at first use ...
     std::vector<hipEvent_t> e_bfork, e_bjoin;      // ... with fork events (4 per part) and one join event per part

@@ -47,6 +47,16 @@ def world(group=None):
     return dist.get_rank(group), dist.get_world_size(group)
 
 
+def broadcast_rank0_int(value, group=None, device="cpu"):
+    """Every rank passes its own value, every rank gets rank 0's (a collective; `device`: where the one-word tensor lives --
+    the GPU under RCCL, the CPU under gloo)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([int(value)], dtype=torch.int32, device=device)
+    dist.broadcast(t, src=0, group=group)
+    return int(t.item())
+
+
 def gather_records(flat, group=None, always=False):
     """The path's only collective: all-gather of the per-rank record buffer.
     flat: [record_words] int32 (device or CPU).  Returns [world, record_words]; rank order == image order.
@@ -69,6 +79,14 @@ def detect_sharded(engine, x_local, threshold, iou_threshold, nms_mode=0, group=
     Returns (boxes [W, B, K, 6], counts [W, B], status [W, B]) as views of the gathered buffer."""
     n_local = 0 if x_local is None else int(x_local.shape[0])
     B = engine.max_batch
+    _, w = world(group)
+    if w > 1 and not getattr(engine, "_streams_agreed", False):
+        # once per engine, on every rank (a collective): all ranks run the plan rank 0 measured -- one pass or two half batches --
+        # instead of each rank's own tuner answer (engine.agree_streams; stand-in engines of the CPU tests have none)
+        agree = getattr(engine, "agree_streams", None)
+        if agree is not None:
+            agree(x_local if n_local else None, group)
+        engine._streams_agreed = True
     if n_local:
         engine.detect(x_local, threshold, iou_threshold, nms_mode)
     if n_local < B:         # records of images this rank did not run: count 0, status 0

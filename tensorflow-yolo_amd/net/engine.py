@@ -73,7 +73,7 @@ class Plan(object):
     Works without a GPU (used by the CPU test-suite to check planning)."""
 
     def __init__(self, net, dtype="fp16", max_batch=1, keep_all=False, cand_capacity=4096, max_boxes=_hip.DEFAULT_MAX_BOXES, streams=0,
-                 force_tile=None):
+                 force_tile=None, guard_bytes=0):
         self.lib = _hip.lib()
         self.layers = list(net)
         known = {"fp16": _hip.DTYPE_F16, "f16": _hip.DTYPE_F16, "half": _hip.DTYPE_F16,
@@ -86,7 +86,7 @@ class Plan(object):
         self.cand_capacity = int(cand_capacity)
         opt = _hip.NetOptions(dtype=self.dtype, max_batch=self.max_batch, keep_all=int(bool(keep_all)),
                               cand_capacity=self.cand_capacity, max_boxes=self.max_boxes, streams=int(streams),
-                              force_tile=0 if force_tile is None else int(force_tile) + 1)
+                              force_tile=0 if force_tile is None else int(force_tile) + 1, guard_bytes=int(guard_bytes))
         descs = to_descs(self.layers)
         handle = C.c_void_p()
         _hip.check(self.lib.yolo_net_create(descs, len(self.layers), C.byref(opt), C.byref(handle)), "yolo_net_create")
@@ -112,6 +112,13 @@ class Plan(object):
         """parts / HIP streams a full batch currently runs as (yolo_net_options.streams; 0 = the library's rule, which a
         HipNetwork re-measures on the device at its first full batch: yolo_net_tune_streams)"""
         return self.lib.yolo_net_num_streams(self.handle)
+
+    def workspace_regions(self):
+        """[(name, offset, used_bytes, region_bytes)] of the planned workspace (yolo_net_workspace_regions: diagnostic / canary tests)."""
+        n = self.lib.yolo_net_workspace_regions(self.handle, None, 0)
+        arr = (_hip.WsRegion * n)()
+        self.lib.yolo_net_workspace_regions(self.handle, arr, n)
+        return [(r.name.decode(), int(r.offset), int(r.used_bytes), int(r.region_bytes)) for r in arr]
 
     def set_head(self, hd):
         _hip.check(self.lib.yolo_net_set_head(self.handle, C.byref(hd)), "yolo_net_set_head")
@@ -194,6 +201,21 @@ class HipNetwork(Plan):
         with self.torch.cuda.device(self.device):
             _hip.check(self.lib.yolo_net_tune_streams(self.handle, x.data_ptr(), x.shape[0], self._stream()), "yolo_net_tune_streams")
         self._streams_tuned = True
+
+    def agree_streams(self, x, group=None):
+        """Ranks of a sharded batch must run the SAME plan: each rank measures for itself where it can, then rank
+        0's answer is broadcast and taken by everyone -- one pass and two halves differ in fp16 summation order, and the job's step
+        time is the slowest rank's.  A collective: every rank calls it once (net/dist.py does, at its first sharded detect)."""
+        torch = self.torch
+        if x is not None and x.shape[0] > 0:
+            self._tune_streams(self.to_device(x))
+        import torch.distributed as dist
+        from . import dist as ydist
+        want = ydist.broadcast_rank0_int(self.num_streams, group, self.device if dist.get_backend(group) == "nccl" else "cpu")
+        if want != self.num_streams:
+            _hip.check(self.lib.yolo_net_set_streams(self.handle, want), "yolo_net_set_streams")
+        self._streams_tuned = True
+        return want
 
     def forward(self, x, out=None):
         """Head logits (float32, device) in the reference's layout: v2 [B,h,w,A*(5+C)], v3 [B,rows,5+C]."""

@@ -45,6 +45,13 @@ class StandInEngine(object):
         self.records = torch.full((ydist.record_words(max_batch, max_boxes),), 12345, dtype=torch.int32)   # stale garbage
         self._boxes, self._counts, self._status = ydist.split_records(self.records, max_batch, max_boxes)
         self.calls = 0
+        self.agreed = []
+
+    def agree_streams(self, x, group=None):
+        """HipNetwork.agree_streams with the measurement replaced by a rank-dependent answer: rank 0 'measures' one pass, the
+        others two halves; everybody must end up with rank 0's."""
+        mine = 1 if dist.get_rank() == 0 else 2
+        self.agreed.append(ydist.broadcast_rank0_int(mine, group))
 
     def detect(self, x, threshold, iou_threshold, nms_mode=0):
         self.calls += 1
@@ -95,7 +102,7 @@ def _worker(rank, world, port, q):
         got1 = model.predict(x[:1], 0.5, 0.6)
         q.put((rank, tuple(boxes.shape), counts.tolist(), status.tolist(), lists,
                [[(b.x, b.y, b.w, b.h, b.class_idx, b.prob) for b in img] for img in got],
-               [[(b.x, b.y, b.w, b.h, b.class_idx, b.prob) for b in img] for img in got1], eng.calls))
+               [[(b.x, b.y, b.w, b.h, b.class_idx, b.prob) for b in img] for img in got1], eng.calls, eng.agreed))
     finally:
         dist.destroy_process_group()
 
@@ -113,7 +120,8 @@ def test_sharded_step_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     want = _expected(TAGS)
-    for rank, shape, counts, status, lists, pred, pred1, calls in got:
+    for rank, shape, counts, status, lists, pred, pred1, calls, agreed in got:
+        assert agreed == [1]        # one agreement per engine (three sharded calls), rank 0's answer on every rank
         assert shape == (2, 3, 6, 6)                                    # [world, B, K, 6]: rank order == image order
         assert counts == [[1, 3, 0], [5, 2, 0]] and status == [[0, 0, 0], [0, 0, 0]]     # the padded slot of rank 1 reads count 0
         flat = [lists[0], lists[1], lists[2], lists[3], lists[4]]       # slots rank-major; slot 5 is the pad

@@ -308,7 +308,7 @@ def test_fused_stem(shape):
     assert ("conv_stem<f16,3-32-64>" in names2) == (H % 2 == 0 and W % 2 == 0) and "3-32-64-32" not in names2, names2
 
 
-@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 24])
+@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15, 16, 17, 18])
 def test_tap_reuse_tile_configs(tile):
     """tap-reuse tiles of conv_tap.hip (3x3/1 only: patch of 1, 2, 4 and 6 channel slices, image borders inside a
     block, position tail; the other layers fall back to the default choice) forced through yolo_net_options.force_tile: K-stage counts 1, 2 (shorter than the
@@ -338,7 +338,7 @@ def test_tap_reuse_tile_configs(tile):
 
 @pytest.mark.parametrize("shape", [(2, 19, 19, 512, 256), (5, 13, 13, 128, 256), (3, 38, 38, 64, 128), (1, 76, 76, 128, 256), (2, 7, 78, 32, 128),
                                    (2, 5, 110, 64, 128), (1, 9, 152, 64, 128), (2, 33, 100, 32, 64), (1, 48, 304, 32, 64), (2, 21, 70, 32, 32)])
-@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 22, 24])
+@pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 22])
 def test_tap_reuse_conv_shapes(shape, tile):
     """conv_tap.hip on the feature-map sizes of YOLOv3-608 (19, 38, 76), the widest rows its padded-linear tiles take
     (78, 110, 158 >= 152), wide maps for the 2-D tiles (partial 16x16 tiles in both directions, Cout 64) and a residual
@@ -357,8 +357,8 @@ def test_tap_reuse_conv_shapes(shape, tile):
         if dict(((11, cout > 64 and W <= 158), (13, cout == 64), (17, cout == 32)))[tile]:
             assert "tap9" in " ".join(ki.name.decode() for ki in eng32.kernel_infos())
     names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
-    max_w = {8: 78, 9: 78, 10: 110, 11: 158, 12: 1 << 20, 13: 1 << 20, 15: 22, 16: 1 << 20, 17: 1 << 20, 18: 19, 22: 13, 24: 78}[tile]
-    need = {8: cout > 64, 9: cout >= 256, 10: cout > 64, 11: cout > 64, 12: cout > 64, 13: cout == 64, 15: cout >= 256, 16: cout > 64, 17: cout == 32, 18: cout > 64 and H == W and W >= 18, 22: cout > 64 and H == W and W >= 12, 24: cout > 64}[tile]
+    max_w = {8: 78, 9: 78, 10: 110, 11: 158, 12: 1 << 20, 13: 1 << 20, 15: 22, 16: 1 << 20, 17: 1 << 20, 18: 19, 22: 13}[tile]
+    need = {8: cout > 64, 9: cout >= 256, 10: cout > 64, 11: cout > 64, 12: cout > 64, 13: cout == 64, 15: cout >= 256, 16: cout > 64, 17: cout == 32, 18: cout > 64 and H == W and W >= 18, 22: cout > 64 and H == W and W >= 12}[tile]
     if W <= max_w and need:             # else: the forced tile is not valid for this layer, the default one runs
         assert "tap9" in names, names
 
@@ -580,3 +580,107 @@ def test_split_k_small_maps(dtype, batch):
     a = eng.forward(x).cpu().numpy()
     for _ in range(3):
         assert np.array_equal(a, eng.forward(x).cpu().numpy()), "in-launch split-K is not repeatable (summation order or ticket counter)"
+
+
+# ---- guard-band canaries -----------------------------------------------------------------------------
+def _guarded_run(net, w, x, dtype, tile=None, keep_all=True, detect=False, guard=4096):
+    """Plan with `guard` never-used bytes behind every tensor, fill the WHOLE workspace with a pattern, run, and require every byte no
+    plan region claims as payload to still hold the pattern: the slack + guard behind each tensor / candidate list / counter block /
+    scratch slab (yolo_net_workspace_regions).  With keep_all no two tensors share bytes; without it (the fused production plan:
+    lifetime-packed arenas) only slack that no other region's payload overlaps can be checked."""
+    import torch
+    from tensorflow_yolo_amd import _hip
+    from tensorflow_yolo_amd.net import engine
+    eng = engine.HipNetwork(net, dtype=dtype, max_batch=x.shape[0], keep_all=keep_all, force_tile=tile, guard_bytes=guard)
+    eng.load_weights(w)
+    ws = eng._workspace
+    ws.fill_(0xA5)
+    _hip.check(eng.lib.yolo_net_bind_workspace(eng.handle, ws.data_ptr(), ws.numel()), "yolo_net_bind_workspace")   # (zeroes the tickets)
+    eng.forward(x)
+    if detect:
+        eng.detect(x, 0.3, 0.6)
+    torch.cuda.synchronize()
+    regions = eng.workspace_regions()
+    payload = sorted((off, off + used) for _, off, used, _ in regions if used)
+    checked = 0
+    for name, off, used, region in regions:
+        lo, hi = off + used, off + region
+        if hi <= lo:
+            continue
+        # cut out what another region's payload covers (lifetime-packed arenas)
+        spans, cur = [], lo
+        for a, b in payload:
+            if b <= cur or a >= hi:
+                continue
+            if a > cur:
+                spans.append((cur, a))
+            cur = max(cur, b)
+            if cur >= hi:
+                break
+        if cur < hi:
+            spans.append((cur, hi))
+        for a, b in spans:
+            bad = (ws[a:b] != 0xA5).nonzero()
+            assert bad.numel() == 0, "%s (tile %s, %s): byte %d behind the payload of a %d-byte region was written\n%s" % (
+                name, tile, dtype, int(bad[0]) + a - lo, used, eng.describe())
+            checked += b - a
+    assert checked >= guard, "nothing to check"
+    return eng, checked
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+@pytest.mark.parametrize("which", ["v2-416", "v3-160", "tiny-v2-416"])
+def test_no_kernel_writes_outside_its_tensor_whole_nets(which, dtype):
+    """every kernel of the three network families (reference net/v2.py:18-59, net/v3.py:22-93; tiny-YOLOv2 from the same vocabulary), both
+    dtypes, forward + detect: with keep_all (one region per tensor, generic kernels) and as the production plan (fused stem, pools,
+    back-to-back 1x1, lifetime-packed arena)"""
+    from oracle import cases
+    from tensorflow_yolo_amd.net import v2, v3
+    names = ["c%d" % i for i in range(80)]
+    if which == "v3-160":
+        net = v3.create_network(np.reshape(cases.COCO_V3_ANCHORS, [-1, 2]), names, False, input_shape=(160, 160, 3))
+        size, batch, nc = 160, 3, 80
+    elif which == "v2-416":
+        net = v2.create_full_network(np.reshape(cases.COCO_V2_ANCHORS, [-1, 2]), names, False, input_shape=(416, 416, 3))
+        size, batch, nc = 416, 2, 80
+    else:
+        net = v2.create_tiny_network(np.reshape(cases.VOC_TINY_ANCHORS, [-1, 2]), names[:20], False, input_shape=(416, 416, 3))
+        size, batch, nc = 416, 2, 20
+    w = synth.darknet_stream(net, seed=31, num_classes=nc, obj_bias=-1.0)
+    x = synth.synthetic_input(batch, size, size, 3, seed=32)
+    total = 0
+    for keep_all in (True, False):
+        eng, checked = _guarded_run(net, w, x, dtype, keep_all=keep_all, detect=(which == "v3-160"))
+        total += checked
+    print("%s %s: %d guard / slack bytes intact" % (which, dtype, total))
+
+
+@pytest.mark.parametrize("tile", list(range(0, 24)))
+def test_no_kernel_writes_outside_its_tensor_every_tile(tile):
+    """every conv tile id (0 = the 4-wave kernel, 1-7 / 14 / 19 LDS-DMA tiles, 8-13 / 15-18 / 22 tap reuse, 20 / 21 / 23 stride-2 tap reuse),
+    forced wherever valid, on graphs whose maps leave position / pixel / cout tails (odd sizes, 255 head channels, 19 x 19 and 13 x 13 maps
+    for the image-aligned tiles): fp16, and float32 where the tile has a float32 instantiation"""
+    shapes = [(3, 20, 24), (2, 19, 19), (2, 13, 13), (1, 38, 38)]
+    total = 0
+    for B, H, W in shapes:
+        g = new_graph(H, W, 3)
+        g.append(PL.conv2d_bn_act(g[-1].out, 32, 3, 1))
+        g.append(PL.conv2d_bn_act(g[-1].out, 64, 3, 1))
+        g.append(PL.conv2d_bn_act(g[-1].out, 128, 3, 1))
+        g.append(PL.conv2d_bn_act(g[-1].out, 64, 1, 1))
+        g.append(PL.conv2d_bn_act(g[-1].out, 128, 3, 1))
+        g.append(PL.shortcut(g[-1].out, g[-3].out))
+        g.append(PL.conv2d_bn_act(g[-1].out, 256, 3, 1))
+        g.append(PL.conv2d_bn_act(g[-1].out, 128, 1, 1))
+        g.append(PL.conv2d_bn_act(g[-1].out, 256, 3, 1))
+        g.append(PL.shortcut(g[-1].out, g[-3].out))
+        if H % 2 == 0 and W % 2 == 0:
+            g.append(PL.conv2d_bn_act(g[-1].out, 512, 3, 2))
+            g.append(PL.conv2d_bn_act(g[-1].out, 256, 1, 1))
+        g.append(PL.conv2d_bn_act(g[-1].out, 255, 1, 1, use_batch_normalization=False, activation_fn="linear"))
+        w = synth.darknet_stream(g, seed=41)
+        x = synth.synthetic_input(B, H, W, 3, seed=42)
+        for dtype in ("fp16", "fp32"):
+            _, checked = _guarded_run(g, w, x, dtype, tile=tile, keep_all=True)
+            total += checked
+    print("tile %d: %d guard / slack bytes intact" % (tile, total))

@@ -14,4 +14,7 @@ cd "$ROOTDIR"
 find "$OUT" -name "*kernel_stats*.csv" | head -3
 f=$(find "$OUT" -name "*kernel_stats*.csv" | head -1)
 [ -n "$f" ] && head -20 "$f"
+# the bench line alone, as JSON (the log also holds rocprofv3's own messages): what profiles/*_bench_under_rocprof.json is copied from
+grep '^{' "$OUT/bench_under_rocprof.log" | tail -1 > "$OUT/bench_under_rocprof.json"
+python3 -c "import json,sys; json.load(open('$OUT/bench_under_rocprof.json')); print('bench line: valid JSON')"
 tail -2 "$OUT/bench_under_rocprof.log"
