@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
+# (YOLO_HIP_LIB: another build of the SAME library -- the sanitizer build of tests/test_sanitizer.py, A/B builds of tools/; no fallback of any kind)
+LIB_PATH = os.environ.get("YOLO_HIP_LIB") or os.path.join(_HERE, "libyolo_hip.so")
 
 ABI_VERSION = 5
 

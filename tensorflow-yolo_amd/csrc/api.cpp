@@ -29,6 +29,10 @@ namespace {
 // images one part of a full batch holds (what every launch of a forward pass sees at most)
 inline int part_batch(const yolo_net *net) { return (net->opt.max_batch + net->parts - 1) / net->parts; }
 const size_t kPairCounterBytes = 65536;            // in-launch pair / split-K (conv_tap.hip): one ticket per tile, a 128-byte line each (512 tiles), in front of the slabs
+
+// packed weights of a kernel; nullptr while no weights are bound (yolo_net_kernel_info / describe build launch parameters of a plan that
+// has none yet: no offset is applied to a null pointer -- found by the sanitizer build, tests/test_sanitizer.py)
+static inline const unsigned char *weights_at(const yolo_net *net, size_t off) { return net->dev_weights ? net->dev_weights + off : nullptr; }
 bool conv_tile_valid(const yolo_net *net, const Kernel &k, int tile);
 size_t splitk_slab_bytes(const yolo_net *net);
 
@@ -235,9 +239,9 @@ int make_conv_params(yolo_net *net, const Kernel &k, const Ptrs &P, int batch, C
         return fail(YOLO_ERR_ARG, "conv input tensor exceeds 2 GiB (32-bit buffer addressing): lower the batch");
     p.in = P.buf_base(in.buf);
     p.in_bytes = (uint32_t)in_bytes;
-    p.wgt = net->dev_weights + k.w_off;
+    p.wgt = weights_at(net, k.w_off);
     p.wgt_bytes = (uint32_t)k.w_bytes;
-    p.bias = reinterpret_cast<const float *>(net->dev_weights + k.b_off);
+    p.bias = reinterpret_cast<const float *>(weights_at(net, k.b_off));
     p.H = in.H; p.W = in.W; p.in_ld = in.ld; p.in_coff = in.coff; p.in_img_stride = in.img_stride;
     const yolo_layer_desc &d = net->layers[k.src_layer].d;
     const int Ho = net->layers[k.src_layer].H, Wo = net->layers[k.src_layer].W;
@@ -488,10 +492,10 @@ bool conv_fuse2(const yolo_net *net, size_t ki, const Ptrs *P, int batch, ConvPa
     const long long ob = (long long)batch * b.out.img_stride * net->esize;
     if (ob <= 0 || ob > 0x7ffffff0LL) return false;
     p.fuse2 = 1;
-    p.w2 = net->dev_weights + b.w_off;
+    p.w2 = weights_at(net, b.w_off);
     p.w2_bytes = (uint32_t)b.w_bytes;
     p.wrow2_bytes = (uint32_t)b.ktiles * 128;
-    p.b2 = reinterpret_cast<const float *>(net->dev_weights + b.b_off);
+    p.b2 = reinterpret_cast<const float *>(weights_at(net, b.b_off));
     p.out2 = P ? P->view_ptr(b.out) : nullptr;
     p.out2_bytes = (uint32_t)ob;
     p.out2_ld = b.out.ld;
