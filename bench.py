@@ -279,6 +279,7 @@ def main():
                     "2..4 = that many parts.  The per-kernel roofline figures are always those of whole-batch launches run alone (streams = 1)")
     ap.add_argument("--no-one-stream-leg", action="store_true", help="skip the one-stream comparison legs around the timed region (N = 1, "
                     "only when the timed engine runs on more than one stream)")
+    ap.add_argument("--f32-products", type=int, default=0, help="yolo_net_options.f32_products (float32 nets): 0 the library's rule, 1 native float32 MFMA everywhere, 2 nine bf16 products wherever possible")
     ap.add_argument("--threshold", type=float, default=0.5)
     ap.add_argument("--iou-threshold", type=float, default=0.6)
     ap.add_argument("--dump-kernels", default=None, help="write the per-kernel timing table (JSON) here")
@@ -308,7 +309,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     kind, size, batch, dtype = WORKLOADS[args.workload]
-    model, w, anchors, ncls = make_model(kind, size, batch, dtype, streams=args.streams, max_boxes=args.max_boxes, force_tile=args.force_tile)
+    model, w, anchors, ncls = make_model(kind, size, batch, dtype, streams=args.streams, max_boxes=args.max_boxes, force_tile=args.force_tile,
+                                         f32_products=args.f32_products)
     eng = model.net.engine
     from tensorflow_yolo_amd.net import synth
     # two different resident input batches, alternated, so no step re-reads the previous step's input
@@ -324,7 +326,7 @@ def main():
     def other_engine(streams):
         m1 = type(model)()
         m1.build(anchors, ["c%d" % i for i in range(ncls)], (size, size, 3), dtype=dtype, max_batch=batch, weights=w, streams=streams,
-                 max_boxes=args.max_boxes, force_tile=args.force_tile)
+                 max_boxes=args.max_boxes, force_tile=args.force_tile, f32_products=args.f32_products)
         return m1.net.engine
 
     def one_stream_engine():
@@ -432,7 +434,11 @@ def main():
                                         if getattr(eng, "_streams_tuned", False) else ""),
                        "sharding": "images over ranks; all-gather of box records only" if world > 1 else "single GPU",
                        "boxes_per_image_last_step": round(float(nboxes.mean()), 1),
-                       "forward_gflop_per_image": round(eng.flops_per_image / 1e9, 3)},
+                       "forward_gflop_per_image": round(eng.flops_per_image / 1e9, 3),
+                       **({"float32_products": "yolo_net_options.f32_products = %d: %d of %d launches multiply as nine bf16 x bf16 products per float32 product "
+                                                "(exact partial products, float32 accumulation; 1 = native float32 MFMA everywhere)"
+                                                % (args.f32_products, sum("conv_igemm_emu" in ki.name.decode() for ki in infos), len(infos))}
+                          if dtype == "fp32" else {})},
             "roofline": roof,
             "forward_frac_of_mfma_peak": round(eng.flops_per_image * total_images / elapsed / 1e12 / (PEAK[dtype] * world), 4),
         })

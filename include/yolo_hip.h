@@ -100,6 +100,12 @@ typedef struct yolo_net_options {
                              * tensor (rounded into the tensor's 4 KiB-aligned region); with keep_all = 1 no two tensors share bytes, so a
                              * pattern-filled workspace shows any kernel that writes outside its tensor (yolo_net_workspace_regions);
                              * 0 in production                                                                                */
+    int32_t f32_products;   /* float32 nets (ABI 5): how the long-K convs of the 4-wave kernel multiply.  0: the library's rule -- whole-K
+                             * launches with K >= 4608 and >= 256 workgroups (tiny-YOLOv2's 13 x 13 512 -> 1024 and 1024 -> 1024 layers) run
+                             * every float32 product as NINE bf16 x bf16 products on the bf16 matrix cores (a float32 value is exactly the
+                             * sum of three bf16 values; each partial product is exact, the sums accumulate in float32: not narrower than
+                             * tf.layers.conv2d's float32, net/layers.py:31-39; 16/9 of the float32 matrix rate); 1: native float32 MFMA
+                             * everywhere; 2: nine bf16 products wherever the kernel applies.  Ignored by fp16 nets.                   */
 } yolo_net_options;
 
 /* Result record; field names follow net/base.py:257-272 BoundingBox. */

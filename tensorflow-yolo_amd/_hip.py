@@ -32,7 +32,7 @@ class LayerDesc(C.Structure):
 
 class NetOptions(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("max_batch", C.c_int32), ("keep_all", C.c_int32),
-                ("cand_capacity", C.c_int32), ("max_boxes", C.c_int32), ("streams", C.c_int32), ("force_tile", C.c_int32), ("guard_bytes", C.c_int32)]
+                ("cand_capacity", C.c_int32), ("max_boxes", C.c_int32), ("streams", C.c_int32), ("force_tile", C.c_int32), ("guard_bytes", C.c_int32), ("f32_products", C.c_int32)]
 
 
 class Box(C.Structure):

@@ -521,6 +521,7 @@ hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParam
             p.part_bytes = (uint32_t)(data_bytes < 0x7ffffff0u ? data_bytes : 0x7ffffff0u);
         }
     }
+    if (tile <= 0) p.f32_emu = conv_f32_emu_rule(net->opt.f32_products, net->opt.dtype, p, k.cfg, k.perchunk != 0, ks) ? 1 : 0;
     hipError_t e = tile > 0 ? launch_conv_dma(p, tile, s) : launch_conv(p, net->opt.dtype, k.cfg, k.perchunk != 0, s);
     if (e != hipSuccess || ks <= 1 || pk.pair) return e;
     ReduceParams r;
@@ -973,9 +974,11 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
             }
             set_symbol(sym);
         } else {
-            set_symbol(conv_symbol(net->opt.dtype, k.cfg, k.perchunk != 0));
-            snprintf(out->name, sizeof out->name, "conv_igemm<%s,N%d,%s>", t, k.cfg == CFG_N128 ? 128 : k.cfg == CFG_N64 ? 64 : 32,
-                     k.perchunk ? "perchunk" : "uniform");
+            const bool emu = conv_f32_emu_rule(net->opt.f32_products, net->opt.dtype, sp, k.cfg, k.perchunk != 0, pk.ks);
+            set_symbol(conv_symbol(net->opt.dtype, k.cfg, k.perchunk != 0, emu));
+            if (emu) snprintf(out->name, sizeof out->name, "conv_igemm_emu<f32 as 9 x bf16,N128>");
+            else snprintf(out->name, sizeof out->name, "conv_igemm<%s,N%d,%s>", t, k.cfg == CFG_N128 ? 128 : k.cfg == CFG_N64 ? 64 : 32,
+                          k.perchunk ? "perchunk" : "uniform");
         }
         if (k.outmode == OUT_POOL2) {
             const size_t n = strlen(out->name);

@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams p) 
     conv_epilogue<T, TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH, m0 + wn * (TP * 16), fr);
 }
 
-// ---- float32 convs on the bf16 matrix cores: every product as nine bf16 x bf16 products (opt-in experiment: YOLO_F32_EMU=1) ----------
+// ---- float32 convs on the bf16 matrix cores: every product as nine bf16 x bf16 products (yolo_net_options.f32_products; round 5: by rule) ----------
 // An fp32 value is EXACTLY the sum of three bf16 values (8 + 8 + 8 mantissa bits, same exponent range): x = h + m + l with
 // h = bf16(x), m = bf16(x - h), l = bf16(x - h - m).  Then a b = sum over the nine (i, j) of a_i b_j, each an exact product of two
 // 8-bit mantissas accumulated in fp32 by mfma_f32_16x16x32_bf16 -- at 16x the rate of mfma_f32_16x16x4f32, i.e. 16 / 9 of the float32
@@ -205,7 +205,9 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams p) 
 // added first; the accumulator is flushed into a second one every 256 k as in the fp32 kernel.  Measured (tiny-YOLOv2-VOC b64, the two
 // 13 x 13 layers that are 65 % of its step): logits 2.0e-5 from the CPU oracle (native fp32 MFMA: 2.2e-5), boxes identical;
 // 1024 -> 1024 1.81 -> 1.59 ms (127 TFLOP/s against the 137 a register-fed mfma_f32_16x16x4f32 loop sustains), step 15.3 k -> 16.7 k
-// img/s.  NOT the default: every number under profiles/ and in bench.py's lines is the native float32 path.
+// img/s.  Round 5: taken BY RULE (conv_f32_emu_rule below) by the long-K whole-K launches of float32 nets -- exact partial products, float32
+// accumulation: the 1e-4 logit contract of the float32 path is asserted with it (tests/test_gpu_nets.py) -- and `f32_products = 1` keeps the
+// native float32 MFMA everywhere (the A/B arm, and what profiles/ up to round 4 measured).
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
@@ -371,8 +373,7 @@ static hipError_t launch_cfg(const ConvParams &p0, int cfg, hipStream_t s) {
     conv_set_divisors(p, p.tiles_per_tap);
     if (p.ksplit > 1 && (!p.part || p.kunits < 1 || (long long)p.ksplit * p.kunits < p.ktiles)) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks, (unsigned)(p.ksplit > 1 ? p.ksplit : 1)), block(256);
-    static const bool emu = getenv("YOLO_F32_EMU") != nullptr;       // experiment: float32 products as nine bf16 products (see above)
-    if (F32 && !PC && emu && cfg == CFG_N128 && p.ksplit <= 1) {
+    if (F32 && !PC && p.f32_emu && cfg == CFG_N128 && p.ksplit <= 1) {
         hipLaunchKernelGGL((conv_igemm_emu_kernel<2, 4, 4, 2>), grid, dim3(512), 0, s, p);
         return hipGetLastError();
     }
@@ -390,8 +391,18 @@ hipError_t launch_conv(const ConvParams &p, int dtype, int cfg, bool perchunk, h
     return perchunk ? launch_cfg<true, true>(p, cfg, s) : launch_cfg<true, false>(p, cfg, s);
 }
 
+// nine bf16 products instead of the float32 MFMA: the 128 x 128 whole-K launches of float32 nets that are matrix-bound -- K of at least
+// 4608 (nine taps x 512 channels) over at least a chip's worth of workgroups -- or, with f32_products = 2, every launch the kernel applies to
+bool conv_f32_emu_rule(int f32_products, int dtype, const ConvParams &p, int cfg, bool perchunk, int ksplit) {
+    if (dtype != YOLO_DTYPE_F32 || perchunk || cfg != CFG_N128 || ksplit > 1 || f32_products == 1) return false;
+    if (f32_products == 2) return true;
+    const long long blocks = ((long long)p.M + 127) / 128 * ((p.Cout + 127) / 128);
+    return (long long)p.ktiles * 32 >= 4608 && blocks >= 256;
+}
+
 // the name rocprofv3's kernel trace prints (yolo_kernel_info.symbol)
-std::string conv_symbol(int dtype, int cfg, bool perchunk) {
+std::string conv_symbol(int dtype, int cfg, bool perchunk, bool f32_emu) {
+    if (f32_emu) return "void yolo::conv_igemm_emu_kernel<2, 4, 4, 2>(yolo::ConvParams)";
     const char *shape = cfg == CFG_N128 ? "2, 2, 4, 4" : cfg == CFG_N64 ? "1, 4, 4, 4" : "1, 4, 2, 4";
     return std::string("void yolo::conv_igemm_kernel<") + (dtype == YOLO_DTYPE_F16 ? "false" : "true") + ", " + shape + ", " +
            (perchunk ? "true" : "false") + ">(yolo::ConvParams)";

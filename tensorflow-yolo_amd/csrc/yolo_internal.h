@@ -131,6 +131,7 @@ struct ConvParams {
     int out2_ld, leaky2;
     long long out2_img_stride;
     int dbg;                   // experiment flags (YOLO_CONV_DBG): 1 skip steady-state DMA, 2 skip MFMA phase
+    int f32_emu;               // conv.hip, float32 nets: this launch multiplies as nine bf16 products (conv_f32_emu_rule)
     int qW, qHW, Mq;           // conv_tap.hip: padded-linear pixel grid, row stride W+1, image stride (H+1)(W+1), total
     int q_stride;              // conv_tap.hip MODE 1: first position of tile m = m * q_stride (positions per tile; qHW for the image-aligned tile)
     int t2_shift;              // conv_tap.hip MODE 2: log2 of the positions per 2-D tile (8: 16 x 16, 7: 8 x 16)
@@ -293,7 +294,9 @@ const char *dma_cfg_symbol(int cfg, bool f32, bool fast = false);      // fast: 
 const char *conv_tap_symbol(int variant, bool f32, bool fast = false);
 std::string dma_cfg_symbol_for(int cfg, bool f32, const ConvParams &p);      // the kernel that runs THIS launch (stream form included)
 const char *conv_tap_stream_symbol(int variant);
-std::string conv_symbol(int dtype, int cfg, bool perchunk);
+std::string conv_symbol(int dtype, int cfg, bool perchunk, bool f32_emu = false);
+// float32 nets: does this launch of the 4-wave kernel run its products as nine bf16 products (yolo_net_options.f32_products)?
+bool conv_f32_emu_rule(int f32_products, int dtype, const ConvParams &p, int cfg, bool perchunk, int ksplit);
 std::string first_symbol(int dtype, int cout, bool pool);
 std::string aux_symbol(int kind, int dtype, bool vec);
 int dma_num_cfgs();

@@ -73,7 +73,7 @@ class Plan(object):
     Works without a GPU (used by the CPU test-suite to check planning)."""
 
     def __init__(self, net, dtype="fp16", max_batch=1, keep_all=False, cand_capacity=4096, max_boxes=_hip.DEFAULT_MAX_BOXES, streams=0,
-                 force_tile=None, guard_bytes=0):
+                 force_tile=None, guard_bytes=0, f32_products=0):
         self.lib = _hip.lib()
         self.layers = list(net)
         known = {"fp16": _hip.DTYPE_F16, "f16": _hip.DTYPE_F16, "half": _hip.DTYPE_F16,
@@ -86,7 +86,8 @@ class Plan(object):
         self.cand_capacity = int(cand_capacity)
         opt = _hip.NetOptions(dtype=self.dtype, max_batch=self.max_batch, keep_all=int(bool(keep_all)),
                               cand_capacity=self.cand_capacity, max_boxes=self.max_boxes, streams=int(streams),
-                              force_tile=0 if force_tile is None else int(force_tile) + 1, guard_bytes=int(guard_bytes))
+                              force_tile=0 if force_tile is None else int(force_tile) + 1, guard_bytes=int(guard_bytes),
+                              f32_products=int(f32_products))
         descs = to_descs(self.layers)
         handle = C.c_void_p()
         _hip.check(self.lib.yolo_net_create(descs, len(self.layers), C.byref(opt), C.byref(handle)), "yolo_net_create")

@@ -56,8 +56,8 @@ def new_graph(h, w, c):
     return g
 
 
-def run_hip(net, weights, x, dtype, keep_all=False, max_batch=None, force_tile=None):
-    eng = engine.HipNetwork(net, dtype=dtype, max_batch=max_batch or x.shape[0], keep_all=keep_all, force_tile=force_tile)
+def run_hip(net, weights, x, dtype, keep_all=False, max_batch=None, force_tile=None, **engine_kw):
+    eng = engine.HipNetwork(net, dtype=dtype, max_batch=max_batch or x.shape[0], keep_all=keep_all, force_tile=force_tile, **engine_kw)
     eng.load_weights(weights)
     out = eng.forward(x).cpu().numpy()
     return out, eng

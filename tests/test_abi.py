@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     assert C.sizeof(_hip.Box) == 24
     assert C.sizeof(_hip.LayerDesc) == 4 * (2 + 4 + 3 + 2 + 3 + 1) + 4 + 8 * 16      # one int of padding before the doubles
-    assert C.sizeof(_hip.NetOptions) == 32
+    assert C.sizeof(_hip.NetOptions) == 36
     assert C.sizeof(_hip.HeadDesc) == 4 * 3 + 4 * 12 + 4 + 8 * 64
 
 

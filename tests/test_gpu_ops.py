@@ -25,10 +25,10 @@ def oracle_out(net, w, x, dtype, keep=None):
     return FR.forward(L, w, x, keep=keep, storage="fp16" if dtype == "fp16" else None)
 
 
-def check_graph(net, x, dtype, seed=0, read=(), max_batch=None, tile=None):
+def check_graph(net, x, dtype, seed=0, read=(), max_batch=None, tile=None, **engine_kw):
     w = synth.darknet_stream(net, seed=seed)
     want, kept = oracle_out(net, w, x, dtype, keep=set(read))
-    got, eng = run_hip(net, w, x, dtype, keep_all=bool(read), max_batch=max_batch, force_tile=tile)
+    got, eng = run_hip(net, w, x, dtype, keep_all=bool(read), max_batch=max_batch, force_tile=tile, **engine_kw)
     assert got.shape == want.shape, (got.shape, want.shape)
     errs = {"final": rel_err(got, want)}
     for i in read:
@@ -521,35 +521,30 @@ def test_in_launch_pair_split_k(dtype, shape):
     assert rel_err(a, whole) <= (2e-3 if dtype == "fp16" else 2e-6)        # same products, K summed in two halves
 
 
-def test_float32_products_as_nine_bf16_products_opt_in():
-    """conv.hip: conv_igemm_emu_kernel (YOLO_F32_EMU=1, not the default): a float32 conv on the bf16 matrix cores -- every operand
-    split exactly into three bf16 values while it is staged, every product as nine bf16 x bf16 MFMA terms accumulated in fp32, small
-    terms first, two-level accumulation every 256 k.  In a process of its own (the library reads the switch once): 13 x 13 maps with
-    K = 4608 and 9216 (the tiny-YOLOv2 layers it was measured on), a 1x1, a stride-2 3x3 and a residual, at the batch where the 4-wave
-    kernel runs whole K; every layer against the oracle at the float32 tolerance of every other test."""
-    import os
-    import subprocess
-    import sys
-    code = r"""
-import sys
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-import test_gpu_ops as T
-from tensorflow_yolo_amd.net import layers as PL, synth
-g = T.new_graph(13, 13, 512)
-g.append(PL.conv2d_bn_act(g[-1].out, 1024, 3, 1))
-g.append(PL.conv2d_bn_act(g[-1].out, 256, 1, 1))
-g.append(PL.conv2d_bn_act(g[-1].out, 1024, 3, 1))
-g.append(PL.shortcut(g[-1].out, g[1].out))
-g.append(PL.conv2d_bn_act(g[-1].out, 512, 3, 2))
-g.append(PL.max_pool2d(g[-1].out, 2, stride=1))
-x = synth.synthetic_input(40, 13, 13, 512, seed=91)
-T.check_graph(g, x, "fp32", seed=17, read=(1, 4, 5), tile=0)      # tile 0 = the 4-wave kernel (whole K at this batch)
-print("EMU OK")
-""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, YOLO_F32_EMU="1", AMD_LOG_LEVEL="0")
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "EMU OK" in out.stdout, out.stdout[-2000:]
+def test_float32_products_as_nine_bf16_products():
+    """conv.hip: conv_igemm_emu_kernel -- a float32 conv on the bf16 matrix cores: every operand split exactly into three bf16 values
+    while it is staged, every product as nine bf16 x bf16 MFMA terms accumulated in fp32, small terms first, two-level accumulation
+    every 256 k (tf.layers.conv2d in float32, net/layers.py:31-39).  yolo_net_options.f32_products: 0 = the library's rule (whole-K
+    launches of the 4-wave kernel with K >= 4608 over >= 256 workgroups: the tiny-YOLOv2 13 x 13 layers), 1 = native float32 MFMA
+    everywhere, 2 = wherever the kernel applies.  13 x 13 maps with K = 4608 and 9216, a 1x1, a stride-2 3x3 and a residual, at the
+    batch where the 4-wave kernel runs whole K; every layer against the oracle at the float32 tolerance of every other test, in all
+    three modes, and the kernels named must be the ones the mode asks for."""
+    g = new_graph(13, 13, 512)
+    g.append(PL.conv2d_bn_act(g[-1].out, 1024, 3, 1))                # 1  K = 4608: by rule
+    g.append(PL.conv2d_bn_act(g[-1].out, 256, 1, 1))                 # 2  K = 1024: only when forced
+    g.append(PL.conv2d_bn_act(g[-1].out, 1024, 3, 1))                # 3  K = 2304: only when forced
+    g.append(PL.shortcut(g[-1].out, g[1].out))                       # 4
+    g.append(PL.conv2d_bn_act(g[-1].out, 1024, 3, 1))                # 5  K = 9216: by rule
+    g.append(PL.conv2d_bn_act(g[-1].out, 512, 3, 2))                 # 6
+    g.append(PL.max_pool2d(g[-1].out, 2, stride=1))                  # 7
+    x = synth.synthetic_input(40, 13, 13, 512, seed=91)
+    counts = {}
+    for mode in (0, 1, 2):
+        eng = check_graph(g, x, "fp32", seed=17, read=(1, 4, 5, 6), tile=0, f32_products=mode)    # tile 0 = the 4-wave kernel (whole K at this batch)
+        counts[mode] = sum("conv_igemm_emu" in ki.name.decode() for ki in eng.kernel_infos())
+        syms = [ki.symbol.decode() for ki in eng.kernel_infos() if "conv_igemm_emu" in ki.name.decode()]
+        assert all(s == "void yolo::conv_igemm_emu_kernel<2, 4, 4, 2>(yolo::ConvParams)" for s in syms), syms
+    assert counts[1] == 0 and counts[0] == 2 and counts[2] > counts[0], counts
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "fp32"])
