@@ -105,7 +105,12 @@ __device__ __forceinline__ void conv_init_acc_bias(const ConvParams &p, float4v 
     }
 }
 
-template <typename T, int TM, int TP, int PADQ = 0, bool BIAS_IN_ACC = false>
+// PIL (conv_tap.hip, round 5: position-interleaved fragments): fragment b of a wave holds the positions m_wave + TP fr + b instead of
+// m_wave + 16 b + fr, so that the three taps of a kernel row share their position fragments (see the kernel).
+template <bool PIL, int TP>
+__device__ __forceinline__ int frag_pos(int m_wave, int b, int fr) { return PIL ? m_wave + TP * fr + b : m_wave + b * 16 + fr; }
+
+template <typename T, int TM, int TP, int PADQ = 0, bool BIAS_IN_ACC = false, bool PIL = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, float4v (&acc)[TM][TP], int cbase, int m_wave, int fr) {
     constexpr int CH = 4 * TM;
     constexpr int EPC = 16 / (int)sizeof(T);
@@ -144,7 +149,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, float4v (&acc
 #pragma unroll
         for (int b = 0; b < TP; ++b) {
             int n, rem, oy, ox;
-            const bool ok = conv_decode_pixel<PADQ>(p, m_wave + b * 16 + fr, n, rem, oy, ox);
+            const bool ok = conv_decode_pixel<PADQ>(p, frag_pos<PIL, TP>(m_wave, b, fr), n, rem, oy, ox);
             // pad / tail lanes read the first pixel's residual (always in range) and ignore it
             const long long ro = ok ? (long long)n * p.res_img_stride + (long long)rem * p.res_ld : 0;
             const T *rp = reinterpret_cast<const T *>(p.res) + ro + cbase;
@@ -156,7 +161,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, float4v (&acc
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
         int n, rem, oy, ox;
-        if (!conv_decode_pixel<PADQ>(p, m_wave + b * 16 + fr, n, rem, oy, ox)) continue;
+        if (!conv_decode_pixel<PADQ>(p, frag_pos<PIL, TP>(m_wave, b, fr), n, rem, oy, ox)) continue;
         float v[CH];
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -235,7 +240,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, float4v (&acc
 // before the first is used, leaky ReLU as mul + max (max(s x, x) with s = 0.1 or 1: no select; the conv kernels are compiled
 // with -fno-honor-nans, so no canonicalisation), + residual in float32 (a code path of its own, no select), ONE rounding, 16-byte stores.  Same values as the generic epilogue for every finite
 // input.  The accumulators start from the bias (conv_init_acc_bias).
-template <int TM, int TP, int PADQ, bool RES>
+template <int TM, int TP, int PADQ, bool RES, bool PIL = false>
 __device__ __forceinline__ void conv_epilogue_fast_body(const ConvParams &p, float4v (&acc)[TM][TP], int cbase, int m_wave, int fr) {
     typedef _Float16 T;
     constexpr int CH = 4 * TM, EPC = 8, NQ = CH / EPC;
@@ -249,7 +254,7 @@ __device__ __forceinline__ void conv_epilogue_fast_body(const ConvParams &p, flo
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
         int n, rem, oy, ox;
-        const bool ok = conv_decode_pixel<PADQ>(p, m_wave + b * 16 + fr, n, rem, oy, ox) && c_ok;
+        const bool ok = conv_decode_pixel<PADQ>(p, frag_pos<PIL, TP>(m_wave, b, fr), n, rem, oy, ox) && c_ok;
         const uint32_t o = (uint32_t)(((long long)n * p.out_img_stride + (long long)rem * p.out_ld + cbase) * 2);
         ooff[b] = ok ? o : YOLO_INVALID_OFF;
         if constexpr (RES) {
@@ -281,10 +286,10 @@ __device__ __forceinline__ void conv_epilogue_fast_body(const ConvParams &p, flo
     }
 }
 
-template <int TM, int TP, int PADQ>
+template <int TM, int TP, int PADQ, bool PIL = false>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvParams &p, float4v (&acc)[TM][TP], int cbase, int m_wave, int fr) {
-    if (p.has_res) conv_epilogue_fast_body<TM, TP, PADQ, true>(p, acc, cbase, m_wave, fr);
-    else conv_epilogue_fast_body<TM, TP, PADQ, false>(p, acc, cbase, m_wave, fr);
+    if (p.has_res) conv_epilogue_fast_body<TM, TP, PADQ, true, PIL>(p, acc, cbase, m_wave, fr);
+    else conv_epilogue_fast_body<TM, TP, PADQ, false, PIL>(p, acc, cbase, m_wave, fr);
 }
 
 // BACK-TO-BACK 1x1 (ConvParams.fuse2): the 1x1 conv that reads this conv's output (Darknet-53: the first layer of the next
@@ -488,13 +493,13 @@ __device__ __forceinline__ void conv_epilogue_pool2(const ConvParams &p, float4v
 
 // Split-K: the wave's raw accumulators (no bias, no activation) go to the float32 slab part[split][pixel][cout_pad]; a lane
 // owns CH contiguous couts of a pixel -> 16-byte stores, 64 contiguous bytes per lane and fragment.
-template <int TM, int TP, int PADQ = 0>
+template <int TM, int TP, int PADQ = 0, bool PIL = false>
 __device__ __forceinline__ void conv_store_partial(const ConvParams &p, float4v (&acc)[TM][TP], int cbase, int m_wave, int fr, int split) {
     if (cbase >= p.cout_pad) return;
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
         int n, rem, oy, ox;
-        if (!conv_decode_pixel<PADQ>(p, m_wave + b * 16 + fr, n, rem, oy, ox)) continue;
+        if (!conv_decode_pixel<PADQ>(p, frag_pos<PIL, TP>(m_wave, b, fr), n, rem, oy, ox)) continue;
         float *dst = p.part + ((size_t)split * (size_t)p.M + (size_t)(n * p.HoWo + rem)) * (size_t)p.cout_pad + cbase;
 #pragma unroll
         for (int a = 0; a < TM; ++a) *reinterpret_cast<float4v *>(dst + 4 * a) = acc[a][b];

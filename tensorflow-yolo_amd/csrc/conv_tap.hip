@@ -27,6 +27,15 @@
 #include "conv_common.h"
 #include <type_traits>
 
+#ifndef YOLO_TAP_ASM_MFMA
+#define YOLO_TAP_ASM_MFMA 1
+#endif
+#ifndef YOLO_TAP_PIL_RECOMPUTE
+#define YOLO_TAP_PIL_RECOMPUTE 0
+#endif
+#ifndef YOLO_TAP_PIL
+#define YOLO_TAP_PIL 1
+#endif
 #ifndef YOLO_TAP_DBG        // timing experiments of tools/ (make EXTRA=-DYOLO_TAP_DBG=..): never set in the product build
 #define YOLO_TAP_DBG 0
 #endif
@@ -53,6 +62,38 @@ __device__ __forceinline__ void tap_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (tap_lds_void *)lds_dst, 16, voff, soff, 0, 0);
 #else
     (void)rsrc; (void)lds_dst; (void)voff; (void)soff;
+#endif
+}
+
+// acc += a . b IN PLACE (D = C).  hipcc's own MFMAs (the builtin) get an untied destination whenever its allocator finds that cheaper
+// locally, and in these fully unrolled K loops the 16 accumulators of a wave then wander through ~20 spare registers (`v_mfma v[38:41], a, b,
+// v[66:69]`): the 128-register tiles spilled patch-DMA offsets for it (reloads behind `vmcnt(0)` inside the loop) and took their weight fragments
+// one at a time.  As an asm statement with a read-write operand the accumulator stays where it is: the dominant tile needs 107 registers
+// instead of 128.  What hipcc does not do for an asm statement (cdna_hip_programming.md 5.7): pad its hazards -- the accumulate chain
+// MFMA -> MFMA on the same D = C needs none, A / B come from LDS reads behind hipcc's own `s_waitcnt`, and tap_mfma_drain() stands between the
+// last MFMA and the epilogue's vector reads of the accumulators.
+template <typename T>
+__device__ __forceinline__ void tap_mfma(float4v &acc, const uint4v &a, const uint4v &b) {
+#if YOLO_TAP_ASM_MFMA && defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (sizeof(T) == 2) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+        return;
+    }
+#endif
+    acc = mma_chunk<T>(a, b, acc);
+}
+
+// between the K loop's last in-place MFMA and the first reader of an accumulator that is not an MFMA: the wait states hipcc would have
+// inserted for its own MFMAs (XDL write -> VALU read, at most 18 for this opcode class), and every accumulator made opaque BEHIND them
+// (volatile statements keep their order), so that no consumer is scheduled above
+template <int TM, int TP>
+__device__ __forceinline__ void tap_mfma_drain(float4v (&acc)[TM][TP]) {
+#if YOLO_TAP_ASM_MFMA && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]));
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) asm volatile("" : "+v"(acc[a][b]));
 #endif
 }
 
@@ -94,6 +135,19 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
     constexpr int S = 3;                    // weight ring slots (9 taps per slice: slot = tap % 3)
     constexpr bool STAG = YOLO_TAP_STAGGER != 0 && !F32 && !SPLITK && TM % 2 == 0 && NW == 8 && MODE == 4 && OCC == 4;    // half-tap stagger of waves 4-7 (below)
     constexpr int TMH = TM / 2;
+    // POSITION-INTERLEAVED FRAGMENTS (round 5; padded-linear fp16 tiles).  profiles/r05_ablation.md section 1: the K loop is bound by the fragment
+    // traffic LDS -> registers (without the reads a launch is 18-22 % shorter; with six per 16 MFMAs instead of eight 7-14 %).  The three taps
+    // of a kernel row read the SAME patch rows shifted by one position.  With fragment b of a wave = the 16 positions w0 + 16 b + fr
+    // (lane row fr) a shift by one position moves data across lanes; with fragment b = the positions w0 + TP fr + b it moves data to the NEXT
+    // FRAGMENT: tap kw of output fragment b needs the input positions w0 + TP fr + (b + kw) = input fragment j = b + kw, and j = TP, TP + 1 are
+    // fragments 0, 1 one lane row further (positions w0 + TP (fr + 1) + ...): TP + 2 fragment reads serve the 3 TP fragment uses of a kernel
+    // row.  12 -> 6 position reads per row at TP = 4: 18 fragment reads per 48 MFMAs instead of 24, no extra registers (fragment j lives in
+    // register set j mod TP; TP and TP + 1 are read into the sets of fragments 0 and 1 when tap kw = 0 / 1 has issued its last MFMA on
+    // them), no vector work.  For a fragment to be 16 CONSECUTIVE LDS rows the patch is stored de-interleaved: patch position R lives in
+    // plane R mod TP at row R / TP (planes of PL rows) -- free, because the LDS-DMA takes a per-lane source offset anyway.  The epilogue's
+    // lane <-> pixel map changes accordingly (conv_common.h: frag_pos).
+    constexpr bool PIL = YOLO_TAP_PIL != 0 && MODE == 1 && !F32;
+    constexpr int PL = (PRG * 16) / TP;             // patch rows per plane
     constexpr int ROWB = 64;
     constexpr int NA = WM * TM * 16;
     constexpr int NB = WN * TP * 16;
@@ -177,8 +231,15 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
             n = t2_n; y = t2_y0 - 1 + pr; x = t2_x0 - 1 + pc;
             ok = g < PRG && pc < 18 && pr < NB / 16 + 2 && t2_n * p.HoWo < p.M && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         } else {
-            const int q = q0 - (p.qW + 1) + g * 16 + lrow;
-            ok = g < PRG && q >= 0 && q < p.Mq;
+            int Rp = g * 16 + lrow;                 // LDS row of the patch buffer -> patch position
+            bool in_planes = true;
+            if constexpr (PIL) {
+                const int plane = Rp / PL, idx = Rp - plane * PL;
+                in_planes = plane < TP;             // (PRG * 16 rows need not be a multiple of TP)
+                Rp = idx * TP + plane;
+            }
+            const int q = q0 - (p.qW + 1) + Rp;
+            ok = g < PRG && in_planes && q >= 0 && q < p.Mq;
             const int qq = ok ? q : 0;
             n = (int)fdiv((uint32_t)qq, p.dqHW);
             const int r = qq - n * p.qHW;
@@ -273,7 +334,46 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < TP; ++b) acc[a][b] = mma_chunk<T>(fa[a], fb[b], acc[a][b]);
+            for (int b = 0; b < TP; ++b) tap_mfma<T>(acc[a][b], fa[a], fb[b]);
+    };
+
+    // position-interleaved fragments (PIL, above): input fragment j of kernel row kh = patch positions u + TP fr, u = kh qW + wave offset + j
+    uint4v G[PIL ? TP : 1];
+    auto g_ptr = [&](int buf, int u) {
+        // (3 (TP + 2) loop-invariant addresses per patch buffer: with the in-place MFMAs the 128-register tiles have the registers to keep
+        // them -- 18 at TP = 4 -- and computing them where they are used cost +35 % vector instructions, +5 % wave cycles: profiles/r05_ablation.md)
+        if constexpr (YOLO_TAP_PIL_RECOMPUTE != 0) asm volatile("" : "+s"(u));
+        const int plane = (int)((unsigned)u % (unsigned)TP), idx0 = (int)((unsigned)u / (unsigned)TP);
+        const int L = plane * PL + idx0 + fr;
+        return smemP + buf * P_BYTES + (L << 6) + ((fq << 4) ^ ((L & 4) << 3));
+    };
+    // The position fragments a tap needs are requested at the END of the tap in front of it, i.e. BEFORE the barrier between them: they
+    // read the PATCH, which is complete and visible a slice ahead and which no DMA overwrites before the slice after next, so they may be
+    // in flight across the barrier -- behind it only the weight fragments (whose DMA the barrier publishes) are waited for.  After tap
+    // kw = 0 / 1: fragment j = TP + kw into the registers of fragment j = kw (dead); after kw = 2: the TP fragments of the next kernel
+    // row (next slice: the other patch buffer).  `nbuf`: the buffer the tap behind this one reads.
+    auto compute_pil = [&](int slot, int buf, int kh, int kw, int nbuf) {
+        if constexpr (PIL) {
+            const unsigned char *A = smem + slot * A_BYTES + a_frag;
+            const int u0 = kh * p.qW + wn * (TP * 16);
+            constexpr int AH = TM >= 4 ? TM / 2 : TM;        // weight fragments in flight at a time (two register sets of TM / 2 at TM = 4, 8)
+            uint4v fa[TM];
+#pragma unroll
+            for (int a0 = 0; a0 < TM; a0 += AH) {
+#pragma unroll
+                for (int a = a0; a < a0 + AH; ++a) fa[a] = *reinterpret_cast<const uint4v *>(A + a * 16 * ROWB);
+#pragma unroll
+                for (int a = a0; a < a0 + AH; ++a)
+#pragma unroll
+                    for (int b = 0; b < TP; ++b) tap_mfma<T>(acc[a][b], fa[a], G[(b + kw) % TP]);
+            }
+            if (kw < 2) G[kw % TP] = *reinterpret_cast<const uint4v *>(g_ptr(buf, u0 + TP + kw));
+            else {
+                const int un = (kh < 2 ? (kh + 1) * p.qW : 0) + wn * (TP * 16);
+#pragma unroll
+                for (int b = 0; b < TP; ++b) G[b] = *reinterpret_cast<const uint4v *>(g_ptr(nbuf, un + b));
+            }
+        }
     };
 
     // HALF-TAP STAGGER (round 5).  All eight waves of a workgroup run the same program between the same barriers, so the two waves
@@ -296,7 +396,7 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
 #pragma unroll
             for (int a = 0; a < TMH; ++a)
 #pragma unroll
-                for (int b = 0; b < TP; ++b) acc[TMH + a][b] = mma_chunk<T>(ha[a], hb[b], acc[TMH + a][b]);
+                for (int b = 0; b < TP; ++b) tap_mfma<T>(acc[TMH + a][b], ha[a], hb[b]);
         }
     };
     auto compute_late = [&](int slot, int buf, int shift) {
@@ -323,7 +423,7 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
 #pragma unroll
             for (int a = 0; a < TMH; ++a)
 #pragma unroll
-                for (int b = 0; b < TP; ++b) acc[a][b] = mma_chunk<T>(fa[a], hb[b], acc[a][b]);
+                for (int b = 0; b < TP; ++b) tap_mfma<T>(acc[a][b], fa[a], hb[b]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < TMH; ++a) ha[a] = *reinterpret_cast<const uint4v *>(A + (TMH + a) * 16 * ROWB);
@@ -426,9 +526,17 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
             if (tap == 0 && more) issue_patch(c + 1, buf ^ 1);
             const int kh = tap / 3, kw = tap - 3 * kh;
             if constexpr (LATE) compute_late(tap % S, buf, TWO_D ? kh * PW + kw : kh * p.qW + kw);
+            else if constexpr (PIL) compute_pil(tap % S, buf, kh, kw, tap == 8 ? buf ^ 1 : buf);
             else compute(tap % S, buf, TWO_D ? kh * PW + kw : kh * p.qW + kw);
         }
     };
+    if constexpr (PIL) {        // the position fragments of the very first tap: the patch is the oldest DMA in flight
+        if (has_a) tap_wait_vm<2 * JA>(); else tap_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int b = 0; b < TP; ++b) G[b] = *reinterpret_cast<const uint4v *>(g_ptr(0, wn * (TP * 16) + b));
+        __builtin_amdgcn_sched_barrier(0);
+    }
     auto run_all = [&](auto latec) {
         if constexpr (STAG) init_acc();
         if constexpr (decltype(latec)::value) {
@@ -458,6 +566,7 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
     } else {
         run_all(std::false_type());
     }
+    if constexpr (!F32) tap_mfma_drain<TM, TP>(acc);
     if constexpr (F32) {
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -471,7 +580,7 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
     if constexpr (SPLITK) {
         if constexpr (TP == 2) {            // (the 128 x 256 instantiation exists for the in-launch pair only)
             if (!p.pair) {
-                conv_store_partial<TM, TP, PADQ>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr, (int)blockIdx.y);
+                conv_store_partial<TM, TP, PADQ, PIL>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr, (int)blockIdx.y);
                 return;
             }
         }
@@ -528,7 +637,7 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
                     for (int b = 0; b < TP; ++b) acc[a][b] += __builtin_bit_cast(float4v, v[b]);
                 }
             }
-            conv_epilogue<T, TM, TP, PADQ, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
+            conv_epilogue<T, TM, TP, PADQ, true, PIL>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
             return;
         }
 #pragma unroll
@@ -541,7 +650,7 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
             for (int b = 0; b < TP; ++b) acc[a][b] += __builtin_bit_cast(float4v, v[b]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        conv_epilogue<T, TM, TP, PADQ, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
+        conv_epilogue<T, TM, TP, PADQ, true, PIL>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
         return;
     } else {
         // (a template mode, not a run-time branch: with the branch in the code the 128 x (16 x 16) tile spilled 28 VGPRs)
@@ -551,8 +660,8 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
             if constexpr (S2) conv_epilogue_fused_1x1<PADQ, false>(p, acc, q0, wm, wn, wave, lane, smem);    // (the stride-2 conv into a stage: no residual)
             else conv_epilogue_fused_1x1<PADQ, true>(p, acc, q0, wm, wn, wave, lane, smem);       // (the residual block's 3x3: with residual)
         }
-        else if constexpr (FAST) conv_epilogue_fast<TM, TP, PADQ>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
-        else conv_epilogue<T, TM, TP, PADQ, true>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
+        else if constexpr (FAST) conv_epilogue_fast<TM, TP, PADQ, PIL>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
+        else conv_epilogue<T, TM, TP, PADQ, true, PIL>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
     }
 #ifdef YOLO_EXPERIMENT
     if (p.trace && tid == 0) {          // YOLO_CONV_TRACE: phase timestamps (100 MHz) + placement of wave 0 of every block
@@ -869,7 +978,9 @@ bool conv_tap_fits(int variant, int W) {
     // (the image-aligned tile: square maps of 17 .. 19 -- a whole image per tile with at least 80 % of the positions real)
     if (conv_tap_image_aligned(variant) && (W * (W + 1) > kTapNB[variant] || W * (W + 1) * 5 < kTapNB[variant] * 4)) return false;
     if (conv_tap_stride2(variant)) return kTapNB[variant] + W + 2 <= kTapPRG[variant] * 16;
-    return kTapNB[variant] + 2 * W + 4 <= kTapPRG[variant] * 16;
+    // (position-interleaved fragments: the patch buffer holds TP planes of PRG * 16 / TP whole rows; TP = positions per tile / 64)
+    const int tp = kTapNB[variant] / 64, rows = YOLO_TAP_PIL ? kTapPRG[variant] * 16 / tp * tp : kTapPRG[variant] * 16;
+    return kTapNB[variant] + 2 * W + 4 <= rows;
 }
 
 // variant id, then the template arguments after F32: WM, WN, TM, TP, PRG, OCC, MODE (written with ", " so that the

@@ -184,7 +184,9 @@ def test_dominant_kernel_register_allocation_is_guarded():
     """The headline kernel sits at the 128-register limit of two workgroups per CU: an innocent-looking edit elsewhere in
     conv_tap.hip (a run-time split-K branch, a tile loop) pushed 46-64 VGPRs to scratch twice in round 2 and doubled its HBM
     writes before the PMC counters showed it.  hipcc's resource remarks for the fp16 instantiations the YOLOv3 step runs:
-    no spill in the K loop's big tiles beyond the 8 epilogue VGPRs of the 128 x 256 tile, occupancy as designed."""
+    no spill in the K loop's big tiles beyond the 8 epilogue VGPRs of the 128 x 256 tile, occupancy as designed.
+    Round 5: with the MFMAs in place (conv_tap.hip: tap_mfma) NO fp16 instantiation of the kernel spills any more -- the fused 1x1 hosts
+    (25-36 registers before), the pooled 2-D tile (18-25) and the 256 x 256 tile (15-28) included; all of them are held to 0 here."""
     import os
     import re
     import subprocess
@@ -214,10 +216,7 @@ def test_dominant_kernel_register_allocation_is_guarded():
         "ILb0ELi4ELi2ELi4ELi7ELi17ELi2ELi1ELb0ELb1ELb0EE": (0, 2),      # 256 x 224
         "ILb0ELi4ELi2ELi4ELi7ELi17ELi2ELi1ELb0ELb0ELb0EE": (0, 2),
         "ILb0ELi2ELi4ELi4ELi6ELi27ELi2ELi1ELb0ELb1ELb0EE": (0, 2),      # 128 x 384, image-aligned (19 x 19 layers)
-        # 128 x 256 stride 2 (parity planes), generic epilogue: the instantiation that runs.  Round 5: with the half-tap stagger of waves 4-7 the
-        # late waves' loop keeps 24 fragment registers across the barrier and the three patch-DMA offsets go to scratch (reloaded at two of a
-        # slice pair's eight patch requests); measured WITH them: -7 % per launch against the unstaggered, spill-free form (profiles/r05_ablation.md)
-        "ILb0ELi2ELi4ELi4ELi4ELi21ELi4ELi4ELb0ELb0ELb0EE": (4, 4),
+        "ILb0ELi2ELi4ELi4ELi4ELi21ELi4ELi4ELb0ELb0ELb0EE": (0, 4),      # 128 x 256 stride 2 (parity planes, half-tap stagger), generic epilogue: the instantiation that runs
         "ILb0ELi2ELi4ELi4ELi6ELi26ELi2ELi4ELb0ELb1ELb0EE": (0, 2),      # 128 x 384 stride 2, image-aligned
         "ILb0ELi2ELi4ELi4ELi3ELi26ELi4ELi1ELb0ELb1ELb0EE": (0, 4),      # 128 x 192
         "ILb0ELi2ELi4ELi4ELi2ELi28ELi4ELi1ELb0ELb1ELb0EE": (0, 4),      # 128 x 128
@@ -225,12 +224,15 @@ def test_dominant_kernel_register_allocation_is_guarded():
         "ILb0ELi2ELi4ELi4ELi4ELi26ELi2ELi1ELb1ELb0ELb0EE": (0, 2),      # 128 x 256 in-launch pair split (one workgroup per CU)
         "ILb0ELi2ELi4ELi4ELi4ELi27ELi4ELi2ELb0ELb1ELb1EE": (0, 4),      # 2-D 128 x 256 + the back-to-back 1x1
     }
+    for name, r in rows.items():       # every fp16 instantiation (first template argument false), whatever it is used for
+        if "conv3x3_tap_kernelILb0E" in name:
+            assert int(r["VGPRs Spill"]) == 0 and int(r["ScratchSize [bytes/lane]"]) == 0, (name, r)
     seen = 0
     for name, r in rows.items():
         for key, (max_spill, occ) in want.items():
             if "conv3x3_tap_kernel" + key in name:
                 seen += 1
-                assert int(r["VGPRs Spill"]) <= max_spill and int(r["Occupancy [waves/SIMD]"]) == occ, (name, r)
+                assert int(r["VGPRs Spill"]) <= max_spill and int(r["Occupancy [waves/SIMD]"]) >= occ, (name, r)
     assert seen == len(want), sorted(rows)
     # the persistent (stream) form: a reload inside its K loop is a `s_waitcnt vmcnt(0)` in the DMA pipeline (round 3: the
     # TP = 4 instantiations spilled 19-23 VGPRs and ran 6-15 % slower than the plain kernel, so only this one exists)

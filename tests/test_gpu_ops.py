@@ -357,7 +357,7 @@ def test_tap_reuse_conv_shapes(shape, tile):
         if dict(((11, cout > 64 and W <= 158), (13, cout == 64), (17, cout == 32)))[tile]:
             assert "tap9" in " ".join(ki.name.decode() for ki in eng32.kernel_infos())
     names = " ".join(ki.name.decode() for ki in eng.kernel_infos())
-    max_w = {8: 78, 9: 78, 10: 110, 11: 158, 12: 1 << 20, 13: 1 << 20, 15: 22, 16: 1 << 20, 17: 1 << 20, 18: 19, 22: 13}[tile]
+    max_w = {8: 78, 9: 78, 10: 109, 11: 158, 12: 1 << 20, 13: 1 << 20, 15: 19, 16: 1 << 20, 17: 1 << 20, 18: 19, 22: 13}[tile]     # (10, 15: whole planes of the position-interleaved patch)
     need = {8: cout > 64, 9: cout >= 256, 10: cout > 64, 11: cout > 64, 12: cout > 64, 13: cout == 64, 15: cout >= 256, 16: cout > 64, 17: cout == 32, 18: cout > 64 and H == W and W >= 18, 22: cout > 64 and H == W and W >= 12}[tile]
     if W <= max_w and need:             # else: the forced tile is not valid for this layer, the default one runs
         assert "tap9" in names, names

@@ -13,8 +13,10 @@ cd /tmp && export TMPDIR=/tmp
 for v in A B; do
   if [ $v = A ]; then cp /tmp/lib_a.so $ROOTDIR/$LIB; else cp "$ROOTDIR/$ALT" $ROOTDIR/$LIB; fi
   i=0
-  for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INST_CYCLES_VMEM" \
-              "SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_MEM_VIOLATIONS SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_ADDR_STALL"; do
+  # (round 5: $3 / $4 = other counter sets for the two passes, e.g. the wave-state counters: "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY ...")
+  P1="${3:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INST_CYCLES_VMEM}"
+  P2="${4:-SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_MEM_VIOLATIONS SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_ADDR_STALL}"
+  for ctrs in "$P1" "$P2"; do
     i=$((i+1))
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/ldsab_$v/pass$i -o p -- python3 "$ROOTDIR/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-one-stream-leg --streams 1 --no-parity > $ROOTDIR/gpurun_out/ldsab/${v}_pass$i.log 2>&1
     echo "$v pass $i rc=$?"
