@@ -808,7 +808,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_stream_kernel(const Conv
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < TP; ++b) acc[a][b] = mma_chunk<T>(fa[a], fb[b], acc[a][b]);
+            for (int b = 0; b < TP; ++b) tap_mfma<T>(acc[a][b], fa[a], fb[b]);
     };
     // epilogue of one tile: leaky, + residual, fp16, 16-byte stores; NQ * TP loads (if any) and NST stores per wave, always
     auto epilogue = [&](int q0, int n0) __attribute__((always_inline)) {
@@ -919,6 +919,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_stream_kernel(const Conv
         }
         after_epi = false;
         if (last_c) {
+            tap_mfma_drain<TM, TP>(acc);
             epilogue(q0_cur, n0_cur);
             if (!more) { done = true; return; }
             it = it_n; q0_cur = q0_nxt; n0_cur = n0_nxt;
@@ -1017,6 +1018,8 @@ const char *conv_tap_symbol(int variant, bool f32, bool fast) {
 // workgroups per CU: with the loop state of the stream they spill (19-23 VGPRs with all four residual fragments in flight, 5-17 with
 // the two-deep residual pipeline the epilogue has for them), reloads land inside the K loop (each a `s_waitcnt vmcnt(0)` that drains
 // the DMA pipeline) and the launches got SLOWER both times: 76 x 76 +15 % / +3 %, 152 x 152 +6.5 % / +13 % (profiles/r03_ablation.md).
+// (round 5: with the MFMAs in place the 128 x 256 tile compiles in this form without a spill -- 123 registers -- and is still slower than the
+// plain kernel: 76 x 76 +3 ... +5 %, 38 x 38 +-0, profiles/r05_ablation.md section 6; so it stays the 64-cout tile's alone)
 #define YOLO_TAP_STREAM_VARIANTS(X) \
     X(5, 1, 8, 4, 2, 27, 4, 2)
 
