@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
     // in flight across the barrier -- behind it only the weight fragments (whose DMA the barrier publishes) are waited for.  After tap
     // kw = 0 / 1: fragment j = TP + kw into the registers of fragment j = kw (dead); after kw = 2: the TP fragments of the next kernel
     // row (next slice: the other patch buffer).  `nbuf`: the buffer the tap behind this one reads.
-    auto compute_pil = [&](int slot, int buf, int kh, int kw, int nbuf) {
+    auto compute_pil = [&](int slot, int buf, int kh, int kw, int nbuf, auto &&issue_dma) {
         if constexpr (PIL) {
             const unsigned char *A = smem + slot * A_BYTES + a_frag;
             const int u0 = kh * p.qW + wn * (TP * 16);
@@ -362,6 +362,9 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
             for (int a0 = 0; a0 < TM; a0 += AH) {
 #pragma unroll
                 for (int a = a0; a < a0 + AH; ++a) fa[a] = *reinterpret_cast<const uint4v *>(A + a * 16 * ROWB);
+                // the tap's DMA requests go out BEHIND the first weight-fragment reads: the reads' latency then covers the requests' issue
+                // (~60-180 cycles each) instead of standing behind it -- nothing else is between the barrier and the tap's first MFMA
+                if (a0 == 0) issue_dma();
 #pragma unroll
                 for (int a = a0; a < a0 + AH; ++a)
 #pragma unroll
@@ -518,16 +521,21 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
             __builtin_amdgcn_sched_barrier(0);
             // (timing experiments, results wrong: YOLO_TAP_DBG 8 = a barrier every third tap only, 16 = none)
             if constexpr (!((YOLO_TAP_DBG & 16) != 0 || ((YOLO_TAP_DBG & 8) != 0 && tap % 3 != 0))) __builtin_amdgcn_s_barrier();
-            {   // weights two taps ahead
-                const int t2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;
-                const int c2 = tap + 2 < 9 ? c : c + 1;
-                if (c2 < C) issue_weights(t2, c2, (tap + 2) % S);
-            }
-            if (tap == 0 && more) issue_patch(c + 1, buf ^ 1);
+            auto issue_dma = [&]() {
+                {   // weights two taps ahead
+                    const int t2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;
+                    const int c2 = tap + 2 < 9 ? c : c + 1;
+                    if (c2 < C) issue_weights(t2, c2, (tap + 2) % S);
+                }
+                if (tap == 0 && more) issue_patch(c + 1, buf ^ 1);
+            };
             const int kh = tap / 3, kw = tap - 3 * kh;
-            if constexpr (LATE) compute_late(tap % S, buf, TWO_D ? kh * PW + kw : kh * p.qW + kw);
-            else if constexpr (PIL) compute_pil(tap % S, buf, kh, kw, tap == 8 ? buf ^ 1 : buf);
-            else compute(tap % S, buf, TWO_D ? kh * PW + kw : kh * p.qW + kw);
+            if constexpr (PIL && !LATE) compute_pil(tap % S, buf, kh, kw, tap == 8 ? buf ^ 1 : buf, issue_dma);
+            else {
+                issue_dma();
+                if constexpr (LATE) compute_late(tap % S, buf, TWO_D ? kh * PW + kw : kh * p.qW + kw);
+                else compute(tap % S, buf, TWO_D ? kh * PW + kw : kh * p.qW + kw);
+            }
         }
     };
     if constexpr (PIL) {        // the position fragments of the very first tap: the patch is the oldest DMA in flight
