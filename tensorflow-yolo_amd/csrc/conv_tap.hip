@@ -30,6 +30,12 @@
 #ifndef YOLO_TAP_ASM_MFMA
 #define YOLO_TAP_ASM_MFMA 1
 #endif
+#ifndef YOLO_TAP_W_FIRST
+#define YOLO_TAP_W_FIRST 1
+#endif
+#ifndef YOLO_TAP_AH_ALL
+#define YOLO_TAP_AH_ALL 1
+#endif
 #ifndef YOLO_TAP_PIL_RECOMPUTE
 #define YOLO_TAP_PIL_RECOMPUTE 0
 #endif
@@ -206,6 +212,25 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
         const int ch = ws * (TM * 16) + g4 * CH + 4 * tm + jj;  // the cout that row holds (see conv_epilogue)
         a_off[j] = (uint32_t)(n0 + ch) * p.wrow_bytes + (uint32_t)(((lane & 3) ^ tap_swz_w(lrow)) << 4);
     }
+    // channel slices of this workgroup: all of them, or one K split's share (split-K, blockIdx.y)
+    const int c_begin = SPLITK ? (int)blockIdx.y * p.kunits : 0;
+    const int C = SPLITK ? ((c_begin + p.kunits < (p.cin_chunks >> 2)) ? c_begin + p.kunits : (p.cin_chunks >> 2)) : (p.cin_chunks >> 2);
+    const int KT = 9 * C;
+    auto issue_weights = [&](int tap, int c, int slot) {
+        const uint32_t ka = (uint32_t)(tap * p.cin_chunks + 4 * c) * 16;
+        if (has_a) {
+#pragma unroll
+            for (int j = 0; j < JA; ++j) tap_dma16(rs_w, smem + slot * A_BYTES + (j * NW + wave) * 1024, a_off[j], ka);
+        }
+    };
+    // (PIL tiles: the first two weight tiles are requested HERE, in front of the patch geometry -- two multiply-shift divisions per patch row
+    // group and lane, ~0.5 us of the 1 us a workgroup spends in setup -- so that their latency runs under it; DMA order W0, W1, patch)
+    constexpr bool W_FIRST = YOLO_TAP_W_FIRST != 0 && YOLO_TAP_PIL != 0 && MODE == 1 && !F32;
+    if constexpr (W_FIRST) {
+        issue_weights(0, c_begin, 0);
+        issue_weights(1, c_begin, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // patch row R <-> position q0 - (W+2) + R; row group g = j NW + wave
     // (the last of a wave's JP row groups may lie beyond the patch: waves >= JP_FULL issue one instruction fewer)
     constexpr int JP_FULL = PRG - (JP - 1) * NW;    // waves that own JP row groups
@@ -252,22 +277,11 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
         b_off[j] = ok ? (uint32_t)(e * (long long)sizeof(T)) + csw_p : YOLO_INVALID_OFF;
     }
 
-    // channel slices of this workgroup: all of them, or one K split's share (split-K, blockIdx.y)
-    const int c_begin = SPLITK ? (int)blockIdx.y * p.kunits : 0;
-    const int C = SPLITK ? ((c_begin + p.kunits < (p.cin_chunks >> 2)) ? c_begin + p.kunits : (p.cin_chunks >> 2)) : (p.cin_chunks >> 2);
-    const int KT = 9 * C;
     auto issue_patch = [&](int c, int buf, uint32_t plane_off = 0u) {
         const uint32_t koff = (uint32_t)c * ROWB + plane_off;
 #pragma unroll
         for (int j = 0; j < JP; ++j)
             if (j + 1 < JP || jp_full) tap_dma16(rs_in, smemP + buf * P_BYTES + (j * NW + wave) * 1024, b_off[j], koff);
-    };
-    auto issue_weights = [&](int tap, int c, int slot) {
-        const uint32_t ka = (uint32_t)(tap * p.cin_chunks + 4 * c) * 16;
-        if (has_a) {
-#pragma unroll
-            for (int j = 0; j < JA; ++j) tap_dma16(rs_w, smem + slot * A_BYTES + (j * NW + wave) * 1024, a_off[j], ka);
-        }
     };
 
     float4v acc[TM][TP];
@@ -356,7 +370,7 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
         if constexpr (PIL) {
             const unsigned char *A = smem + slot * A_BYTES + a_frag;
             const int u0 = kh * p.qW + wn * (TP * 16);
-            constexpr int AH = TM >= 4 ? TM / 2 : TM;        // weight fragments in flight at a time (two register sets of TM / 2 at TM = 4, 8)
+            constexpr int AH = YOLO_TAP_AH_ALL ? TM : (TM >= 4 ? TM / 2 : TM);        // weight fragments in flight at a time (two register sets of TM / 2 at TM = 4, 8)
             uint4v fa[TM];
 #pragma unroll
             for (int a0 = 0; a0 < TM; a0 += AH) {
@@ -455,6 +469,8 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
         issue_patch(c_begin, 0, pl10 + pl01);
         issue_weights(0, c_begin, 0);
         issue_weights(2, c_begin, 1);
+    } else if constexpr (W_FIRST) {
+        issue_patch(c_begin, 0);        // (the weights are on their way: above)
     } else {
         issue_patch(c_begin, 0);
         issue_weights(0, c_begin, 0);
@@ -538,8 +554,8 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
             }
         }
     };
-    if constexpr (PIL) {        // the position fragments of the very first tap: the patch is the oldest DMA in flight
-        if (has_a) tap_wait_vm<2 * JA>(); else tap_wait_vm<0>();
+    if constexpr (PIL) {        // the position fragments of the very first tap: the patch is the oldest DMA in flight (W_FIRST: the youngest)
+        if (has_a && !W_FIRST) tap_wait_vm<2 * JA>(); else tap_wait_vm<0>();
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int b = 0; b < TP; ++b) G[b] = *reinterpret_cast<const uint4v *>(g_ptr(0, wn * (TP * 16) + b));
