@@ -124,3 +124,23 @@ def test_per_class_trace_matches_per_class_nms():
     boxes = _hip_like(c, head, kw, per_class=True)
     rep = parity.check(head, head, boxes, 3, c["threshold"], c["iou"], per_class=True, **kw)
     assert rep["box_set_match"] and rep["boxes_unexplained"] == 0 and rep["nms_mode"] == "per_class"
+
+
+def test_score_ties_within_float32_rounding_may_swap_and_nothing_else():
+    """Two boxes whose scores differ by one float32 ulp may come out in either order (NumPy's float32 exp and the GPU's expf are both a
+    few ulp accurate and not the same function; the reference's stable sort then breaks the tie by scan order on one side only):
+    `_match_with_ties` accepts that permutation, counts it, and still rejects a swap of boxes whose scores are further apart, a changed
+    box, or a missing one."""
+    p0 = float(np.float32(0.50947118))
+    p1 = float(np.nextafter(np.float32(p0), np.float32(1.0)))           # one ulp above
+    a = (0.10, 0.20, 0.30, 0.40, 3, p1)
+    b = (0.60, 0.70, 0.05, 0.06, 7, p0)
+    c = (0.80, 0.10, 0.02, 0.02, 1, 0.40)
+    assert parity._match_with_ties([a, b, c], [a, b, c], 2e-5, 2e-6) == (0, 0)
+    bad, swaps = parity._match_with_ties([b, a, c], [a, b, c], 2e-5, 2e-6)
+    assert (bad, swaps) == (0, 2)                                       # both positions of the tied pair matched across
+    far = (0.60, 0.70, 0.05, 0.06, 7, p0 - 1e-5)
+    assert parity._match_with_ties([far, a, c], [a, far, c], 2e-5, 2e-6)[0] > 0          # 1e-5 apart: a real order error
+    other = (0.61, 0.70, 0.05, 0.06, 7, p0)
+    assert parity._match_with_ties([other, a, c], [a, b, c], 2e-5, 2e-6)[0] > 0          # not the same box
+    assert parity._match_with_ties([a, c], [a, b, c], 2e-5, 2e-6)[0] > 0
