@@ -355,7 +355,7 @@ int choose_ksplit(const Kernel &k, const ConvParams &p, int tile, size_t slab_by
 // What one conv launch runs: the tile (0 = the 4-wave kernel of conv.hip with the planner's cfg, > 0 = conv_dma.hip tile id) and
 // the K split (ks = 1: whole K).  tile_req < 0: the rules of choose_dma_cfg.  One function for the launch path, the workspace
 // sizing (split-K slab) and yolo_net_kernel_info, so what is reported is what runs.
-struct ConvPick { int tile, ks, ku, pair, tail; };      // tail: tiles of the last, at most half-full round that run as two half-K workgroups each (conv_tap.hip MODE 5)
+struct ConvPick { int tile, ks, ku, pair; };
 const size_t kSplitkSlabMax = (size_t)64 << 20;     // per arena
 
 ConvPick pick_conv(const yolo_net *net, const Kernel &k, const ConvParams &p, int tile_req, size_t slab_bytes) {
@@ -427,18 +427,7 @@ ConvPick pick_conv(const yolo_net *net, const Kernel &k, const ConvParams &p, in
         const long long nb11 = (mq + 127) / 128 * ((p.Cout + 127) / 128);
         if (nb11 * 128 <= (long long)kPairCounterBytes && (size_t)nb11 * (size_t)ks * 65536 <= slab_bytes) pair = 1;
     }
-    // TAIL SPLIT (round 5): a whole-K launch of the two-per-CU 128 x 256 tap tile whose last round fills at most half of the 512 slots runs
-    // that round one workgroup per CU at 0.54 of the pair rate (profiles/r05_block_trace.md).  Those tiles are computed by two half-K
-    // workgroups each, dispatched last (YOLOv3-608 b32 38 x 38: 764 tiles = 512 + 252 -> 512 + 504; YOLOv3-416 b32 52 x 52: 704 = 512 + 192).
-    int tail = 0;
-    static const bool no_tail = getenv("YOLO_NO_TAIL_SPLIT") != nullptr;       // A/B switch (same results up to fp32 summation order)
-    if (!no_tail && tile == 8 && ks <= 1 && !pair && !p.f32 && tile_req <= 0 && (p.cin_chunks >> 3) >= 4 && p.HoWo > 0 && p.stride == 1) {
-        const long long mq = (long long)(p.M / p.HoWo) * (p.H + 1) * (p.W + 1);
-        const long long T = (mq + 255) / 256 * ((p.Cout + 127) / 128);
-        const long long r = T % 512;
-        if (T > 512 && r > 0 && r <= 256 && (size_t)r * 2 * 131072 <= slab_bytes) tail = (int)r;
-    }
-    return ConvPick{tile, ks, ku, pair, tail};
+    return ConvPick{tile, ks, ku, pair};
 }
 
 // the shape fields pick_conv reads, for a batch, without device pointers (workspace sizing, kernel_info)
@@ -480,9 +469,6 @@ size_t splitk_slab_bytes(const yolo_net *net) {
                 if (bytes > need) need = bytes;
             } else if (pk.ks > 1) {
                 const size_t bytes = (size_t)pk.ks * (size_t)p.M * (size_t)((p.Cout + 127) / 128 * 128) * 4;
-                if (bytes > need) need = bytes;
-            } else if (pk.tail > 0) {
-                const size_t bytes = (size_t)pk.tail * 2 * 131072;
                 if (bytes > need) need = bytes;
             }
         }
@@ -534,13 +520,6 @@ hipError_t launch_conv_any(const yolo_net *net, const Kernel &k, const ConvParam
             p.pair_cnt = reinterpret_cast<int *>(base);
             p.part_bytes = (uint32_t)(data_bytes < 0x7ffffff0u ? data_bytes : 0x7ffffff0u);
         }
-    }
-    if (pk.tail > 0 && conv_fast_epilogue_ok(p0) && !p.fuse2) {      // tail split: tickets + slabs like the in-launch pair
-        unsigned char *base = net->dev_ws + net->splitk_off + (size_t)arena * slab;
-        p.tail_split = pk.tail;
-        p.part = reinterpret_cast<float *>(base + kPairCounterBytes);
-        p.pair_cnt = reinterpret_cast<int *>(base);
-        p.part_bytes = (uint32_t)(data_bytes < 0x7ffffff0u ? data_bytes : 0x7ffffff0u);
     }
     if (tile <= 0) p.f32_emu = conv_f32_emu_rule(net->opt.f32_products, net->opt.dtype, p, k.cfg, k.perchunk != 0, ks) ? 1 : 0;
     hipError_t e = tile > 0 ? launch_conv_dma(p, tile, s) : launch_conv(p, net->opt.dtype, k.cfg, k.perchunk != 0, s);
@@ -992,14 +971,6 @@ int yolo_net_kernel_info(const yolo_net *net, int kernel, yolo_kernel_info *out)
                 if (pk.pair && occ != std::string::npos) sym.replace(occ, 30, "26, 2, 1, true, false, false>(");
                 const size_t occ22 = sym.find("14, 4, 1, true, false, false>(");     // ... and on the image-aligned 128 x 192 tile
                 if (pk.pair && occ22 != std::string::npos) sym.replace(occ22, 30, "14, 2, 1, true, false, false>(");
-            }
-            if (pk.tail > 0 && pk.ks <= 1) {       // tail split: the MODE 5 instantiation (lean epilogue); else the plain launch runs
-                const size_t at = sym.find("26, 4, 1, false, true, false>(");
-                if (at != std::string::npos) {
-                    sym.replace(at, 30, "26, 4, 5, false, true, false>(");
-                    const size_t n = strlen(out->name);
-                    snprintf(out->name + n, sizeof out->name - n, "+tailK%d", pk.tail);
-                }
             }
             set_symbol(sym);
         } else {

@@ -529,11 +529,6 @@ hipError_t launch_conv_dma(const ConvParams &p0, int cfg, hipStream_t s) {
         if (qblocks <= 0 || qblocks > 0x7fffffffLL) return hipErrorInvalidValue;
         p.Mq = (int)mq;
         p.n_blocks = (int)qblocks;
-        p.n_whole = p.n_split = 0;
-        if (p.tail_split > 0 && p.tail_split < (int)qblocks && cfg == 8) {      // tail split (conv_tap.hip MODE 5): api.cpp pick_conv asked for it
-            p.n_split = p.tail_split;
-            p.n_whole = (int)qblocks - p.tail_split;
-        }
         conv_set_divisors(p, p.cin_chunks / k.bkc);
 #ifdef YOLO_EXPERIMENT
         if (getenv("YOLO_CONV_TRACE")) return launch_traced(p, cfg, s);

@@ -136,14 +136,6 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
     typedef typename std::conditional<F32, float, _Float16>::type T;
     constexpr bool TWO_D = MODE == 2 || MODE == 3;       // MODE 3: the 2-D tiles of MODE 2 with the max-pool behind the conv taken in the epilogue
     constexpr bool S2 = MODE == 4;          // 3x3 / stride 2 over the four parity planes of the input (see run_slice_s2 below)
-    // MODE 5 = MODE 1 + TAIL SPLIT (round 5).  A launch of T tiles on the chip's 512 slots whose last round is at most half full runs that round
-    // one workgroup per CU -- at 0.54 of the rate a pair reaches (profiles/r05_block_trace.md: 38 x 38 at batch 32, 764 tiles: 49 us shared
-    // + 45 us alone).  Here the last n_split tiles are computed by TWO half-K workgroups each, dispatched behind the n_whole whole-K ones
-    // (blockIdx order = longest jobs first): the second round is full again, at half the length.  The halves meet like the in-launch pair
-    // (write-through slab, drained, ticket; the second arriver adds the first one's slab and runs the epilogue).
-    constexpr bool LIN = MODE == 1 || MODE == 5;
-    constexpr bool TAILK = MODE == 5;
-    static_assert(!TAILK || (FAST && !F32 && !SPLITK && !FUSE2), "tail split: the lean fp16 instantiation");
     constexpr int PADQ = TWO_D ? 2 : 1;
     constexpr int NW = WM * WN;
     constexpr int S = 3;                    // weight ring slots (9 taps per slice: slot = tap % 3)
@@ -160,7 +152,7 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
     // them), no vector work.  For a fragment to be 16 CONSECUTIVE LDS rows the patch is stored de-interleaved: patch position R lives in
     // plane R mod TP at row R / TP (planes of PL rows) -- free, because the LDS-DMA takes a per-lane source offset anyway.  The epilogue's
     // lane <-> pixel map changes accordingly (conv_common.h: frag_pos).
-    constexpr bool PIL = YOLO_TAP_PIL != 0 && LIN && !F32;
+    constexpr bool PIL = YOLO_TAP_PIL != 0 && MODE == 1 && !F32;
     constexpr int PL = (PRG * 16) / TP;             // patch rows per plane
     constexpr int ROWB = 64;
     constexpr int NA = WM * TM * 16;
@@ -199,17 +191,7 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    int bid, half_idx = 0;
-    bool halfk = false;                 // (tail split: this workgroup computes half the K range of its tile)
-    if constexpr (TAILK) {
-        halfk = (int)blockIdx.x >= p.n_whole;
-        if (!halfk) bid = xcd_remap(blockIdx.x, p.n_whole);
-        else {
-            const int h = (int)blockIdx.x - p.n_whole;
-            half_idx = h & 1;
-            bid = p.n_whole + xcd_remap(h >> 1, p.n_split);
-        }
-    } else bid = xcd_remap(blockIdx.x, p.n_blocks);
+    const int bid = xcd_remap(blockIdx.x, p.n_blocks);
     const int mt = (int)fdiv((uint32_t)bid, p.dtiles_n);
     const int nt = bid - mt * p.n_tiles_n;
     const int n0 = nt * NA;
@@ -231,9 +213,8 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
         a_off[j] = (uint32_t)(n0 + ch) * p.wrow_bytes + (uint32_t)(((lane & 3) ^ tap_swz_w(lrow)) << 4);
     }
     // channel slices of this workgroup: all of them, or one K split's share (split-K, blockIdx.y)
-    const int c_begin = SPLITK ? (int)blockIdx.y * p.kunits : (TAILK && halfk && half_idx) ? (p.cin_chunks >> 3) : 0;
-    const int C = SPLITK ? ((c_begin + p.kunits < (p.cin_chunks >> 2)) ? c_begin + p.kunits : (p.cin_chunks >> 2))
-                         : (TAILK && halfk && !half_idx) ? (p.cin_chunks >> 3) : (p.cin_chunks >> 2);
+    const int c_begin = SPLITK ? (int)blockIdx.y * p.kunits : 0;
+    const int C = SPLITK ? ((c_begin + p.kunits < (p.cin_chunks >> 2)) ? c_begin + p.kunits : (p.cin_chunks >> 2)) : (p.cin_chunks >> 2);
     const int KT = 9 * C;
     auto issue_weights = [&](int tap, int c, int slot) {
         const uint32_t ka = (uint32_t)(tap * p.cin_chunks + 4 * c) * 16;
@@ -244,7 +225,7 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
     };
     // (PIL tiles: the first two weight tiles are requested HERE, in front of the patch geometry -- two multiply-shift divisions per patch row
     // group and lane, ~0.5 us of the 1 us a workgroup spends in setup -- so that their latency runs under it; DMA order W0, W1, patch)
-    constexpr bool W_FIRST = YOLO_TAP_W_FIRST != 0 && YOLO_TAP_PIL != 0 && LIN && !F32;
+    constexpr bool W_FIRST = YOLO_TAP_W_FIRST != 0 && YOLO_TAP_PIL != 0 && MODE == 1 && !F32;
     if constexpr (W_FIRST) {
         issue_weights(0, c_begin, 0);
         issue_weights(1, c_begin, 1);
@@ -321,11 +302,6 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
 #pragma unroll
                     for (int b = 0; b < TP; ++b) acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
             }
-        } else if (TAILK && halfk && half_idx) {          // (tail split: the bias rides in half 0)
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TP; ++b) acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
         } else {
             conv_init_acc_bias<TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH);
         }
@@ -701,47 +677,6 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
         conv_epilogue<T, TM, TP, PADQ, true, PIL>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
         return;
     } else {
-        if constexpr (TAILK) {
-            if (halfk) {            // the two halves of a tail tile meet (the protocol of the in-launch pair above)
-                constexpr uint32_t SLAB = (uint32_t)NA * NB * 4;
-                const __amdgpu_buffer_rsrc_t rs_part = __builtin_amdgcn_make_buffer_rsrc(p.part, 0, p.part_bytes, 0x00020000);
-                const uint32_t slot = (uint32_t)(bid - p.n_whole);
-                const uint32_t mine = (slot * 2u + (uint32_t)half_idx) * SLAB, other = (slot * 2u + (uint32_t)(1 - half_idx)) * SLAB;
-                typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u4;
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TP; ++b)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc[a][b]), rs_part,
-                                                               mine + (uint32_t)((((wave * TM + a) * TP + b) * 64 + lane) * 16), 0, 16 /* sc1 */);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave
-                __syncthreads();                                        // ... and nobody reads the LDS rings any more
-                int *const flag = reinterpret_cast<int *>(smem);
-                if (tid == 0) {
-                    int *const ticket = p.pair_cnt + (size_t)slot * kCandCountStride;
-                    const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (t == 1) {
-                        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    *flag = t;
-                }
-                __syncthreads();
-                if (*flag != 1) return;         // the first arriver: its share is published
-#pragma unroll
-                for (int a = 0; a < TM; ++a) {
-                    u4 v[TP];
-#pragma unroll
-                    for (int b = 0; b < TP; ++b)
-                        v[b] = __builtin_amdgcn_raw_buffer_load_b128(rs_part, other + (uint32_t)((((wave * TM + a) * TP + b) * 64 + lane) * 16), 0, 16 /* sc1 */);
-#pragma unroll
-                    for (int b = 0; b < TP; ++b) acc[a][b] += __builtin_bit_cast(float4v, v[b]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            conv_epilogue_fast<TM, TP, PADQ, PIL>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
-        } else
         // (a template mode, not a run-time branch: with the branch in the code the 128 x (16 x 16) tile spilled 28 VGPRs)
         if constexpr (MODE == 3) conv_epilogue_pool2<T, TM, TP>(p, acc, n0 + wm * (TM * 16) + fq * CH, q0 + wn * (TP * 16), fr);
         else if constexpr (FUSE2) {
@@ -1158,14 +1093,6 @@ hipError_t launch_conv_tap(const ConvParams &p0, int variant, hipStream_t s) {
     if (p.outmode == OUT_POOL2 && ((variant != 4 && variant != 5 && variant != 8) || (p.H & 1) || (p.W & 1) || p.has_res || p.ksplit > 1 || !p.vec_out || p.Cout % 16))
         return hipErrorInvalidValue;        // the fused pool lives in the 2-D tiles' epilogue only (plan.cpp asks for it accordingly)
     if (p.stream && conv_tap_stream_ok(p, variant)) return launch_conv_tap_stream(p, variant, s);
-    if (p.n_split > 0) {        // tail split (MODE 5): variant 0, lean epilogue, whole K
-        if (variant != 0 || !p.fast_epi || p.ksplit > 1 || p.fuse2 || p.outmode != OUT_NORMAL || p.n_whole < 1 || p.n_whole + p.n_split != p.n_blocks ||
-            p.n_split > 512 || !p.part || !p.pair_cnt || (p.cin_chunks >> 3) < 1 ||
-            (unsigned long long)p.n_split * 2ull * 128ull * 256ull * 4ull > p.part_bytes)
-            return hipErrorInvalidValue;
-        hipLaunchKernelGGL((conv3x3_tap_kernel<false, 2, 4, 4, 4, 26, 4, 5, false, true>), dim3((unsigned)(p.n_whole + 2 * p.n_split)), dim3(512), 0, s, p);
-        return hipGetLastError();
-    }
     const dim3 grid((unsigned)p.n_blocks, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
     if (p.ksplit > 1) {     // split-K instantiation (128 x 128 tile)
         if (!(p.pair ? conv_tap_pair_ok(variant, p.f32 != 0) : conv_tap_splitk_ok(variant)) || !p.part || p.kunits < 1 ||

@@ -109,7 +109,6 @@ struct ConvParams {
     int leaky, has_res, outmode, out_f32, vec_out, vec_res;
     int f32;                   // elements of input / weights / residual are float32 (else fp16)
     int n_tiles_n, n_blocks;
-    int n_whole, n_split, tail_split;   // conv_tap.hip MODE 5 (tail split): tiles [0, n_whole) run whole K, the last n_split tiles as two half-K workgroups each (tail_split: what pick_conv asks for)
     // split-K (small feature maps at small batch: a handful of tiles, each with a K of thousands): blockIdx.y = split s runs
     // K units [s * kunits, (s + 1) * kunits) (conv_tap.hip: channel slices; conv.hip: K tiles) and stores its raw float32
     // accumulators to part[s][pixel][cout_pad]; splitk_reduce_kernel (aux.hip) sums them and runs the fused epilogue
