@@ -985,6 +985,7 @@ __global__ void __launch_bounds__(512, OCC) conv3x3_tap_stream_kernel(const Conv
 // shifts instead of LDS reads, correct and +5 ... +9 % slower)
 static const int kTapNB[] = {256, 256, 192, 128, 256, 256, 224, 128, 256, 384, 256, 384, 192, 256};
 static const int kTapPRG[] = {26, 26, 26, 28, 27, 27, 17, 12, 27, 27, 21, 26, 14, 26};
+static const int kTapTP[] = {4, 4, 3, 2, 4, 2, 7, 2, 2, 6, 4, 6, 3, 4};        // TP of the variant (YOLO_TAP_VARIANTS below): position fragments per wave
 static const int kTapVariants = 14;
 static const bool kTapF32[] = {false, false, false, true, false, true, false, false, true, false, false, false, false, false};      // float32 tiles: TP <= 2 (second-level accumulator)
 bool conv_tap_image_aligned(int variant) { return variant == 9 || variant == 11 || variant == 12; }
@@ -1003,8 +1004,8 @@ bool conv_tap_fits(int variant, int W) {
     // (the image-aligned tile: square maps of 17 .. 19 -- a whole image per tile with at least 80 % of the positions real)
     if (conv_tap_image_aligned(variant) && (W * (W + 1) > kTapNB[variant] || W * (W + 1) * 5 < kTapNB[variant] * 4)) return false;
     if (conv_tap_stride2(variant)) return kTapNB[variant] + W + 2 <= kTapPRG[variant] * 16;
-    // (position-interleaved fragments: the patch buffer holds TP planes of PRG * 16 / TP whole rows; TP = positions per tile / 64)
-    const int tp = kTapNB[variant] / 64, rows = YOLO_TAP_PIL ? kTapPRG[variant] * 16 / tp * tp : kTapPRG[variant] * 16;
+    // (position-interleaved fragments: the patch buffer holds TP planes of PRG * 16 / TP whole rows)
+    const int tp = kTapTP[variant], rows = YOLO_TAP_PIL ? kTapPRG[variant] * 16 / tp * tp : kTapPRG[variant] * 16;
     return kTapNB[variant] + 2 * W + 4 <= rows;
 }
 

@@ -336,7 +336,7 @@ def test_tap_reuse_tile_configs(tile):
     assert "tap9" in names, names
 
 
-@pytest.mark.parametrize("shape", [(2, 19, 19, 512, 256), (5, 13, 13, 128, 256), (3, 38, 38, 64, 128), (1, 76, 76, 128, 256), (2, 7, 78, 32, 128),
+@pytest.mark.parametrize("shape", [(2, 19, 19, 512, 256), (2, 20, 21, 128, 256), (5, 13, 13, 128, 256), (3, 38, 38, 64, 128), (1, 76, 76, 128, 256), (2, 7, 78, 32, 128),
                                    (2, 5, 110, 64, 128), (1, 9, 152, 64, 128), (2, 33, 100, 32, 64), (1, 48, 304, 32, 64), (2, 21, 70, 32, 32)])
 @pytest.mark.parametrize("tile", [8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 22])
 def test_tap_reuse_conv_shapes(shape, tile):

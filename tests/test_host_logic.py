@@ -364,3 +364,22 @@ def test_draw_boxes_content(tmp_path):
     inner = np.zeros((H, W), bool)
     inner[32:89, 62:139] = True; inner[2:59, 2:49] = True                              # box interiors stay as they were
     assert (img[inner] == 17).all()
+
+
+def test_tap_variant_tables_agree_with_the_instantiation_list():
+    """conv_tap.hip: kTapNB / kTapTP (what conv_tap_fits sizes the position-interleaved patch planes with) against the template arguments of
+    YOLO_TAP_VARIANTS -- positions per tile = WN x TP x 16; a wrong TP lets a map through whose patch does not fit its planes (round 5: the
+    256 x 224 tile is 2 x 7 fragments wide, not 224 / 64)."""
+    import os
+    import re
+    src = open(os.path.join(ROOT, "tensorflow-yolo_amd", "csrc", "conv_tap.hip")).read()
+    tp = [int(v) for v in re.search(r"kTapTP\[\] = \{([^}]*)\}", src).group(1).split(",")]
+    nb = [int(v) for v in re.search(r"kTapNB\[\] = \{([^}]*)\}", src).group(1).split(",")]
+    prg = [int(v) for v in re.search(r"kTapPRG\[\] = \{([^}]*)\}", src).group(1).split(",")]
+    block = src[src.index("#define YOLO_TAP_VARIANTS(X)"):src.index("const char *conv_tap_symbol")]
+    seen = 0
+    for m in re.finditer(r"X\((\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\)", block):
+        i, wm, wn, tm, t, g, occ, mode = (int(v) for v in m.groups())
+        assert tp[i] == t and nb[i] == wn * t * 16 and prg[i] == g, (i, tp[i], t, nb[i], wn * t * 16, prg[i], g)
+        seen += 1
+    assert seen == len(tp) == len(nb) == len(prg) == 14
