@@ -40,14 +40,10 @@ size_t splitk_slab_bytes(const yolo_net *net);
 // and again after any failed forward (a launch that did not run may leave the forward half-way).  The memset goes to the null
 // stream, which does not order against the non-blocking streams a caller may launch on: hence the device-wide synchronise.
 int zero_pair_counters(yolo_net *net) {
-    if ((!net->splitk_bytes && !net->chain_bytes) || !net->dev_ws) return YOLO_OK;
-    if (net->splitk_bytes) {
-        const size_t per = net->splitk_bytes / (size_t)net->arenas;
-        for (int a = 0; a < net->arenas; ++a)
-            HIP_TRY(hipMemset(net->dev_ws + net->splitk_off + (size_t)a * (per / 256 * 256), 0, per < kPairCounterBytes ? per : kPairCounterBytes));
-    }
-    // ... and the queue heads / completion counters of the chained launches (conv_chain.hip), which every launch returns to zero as well
-    for (size_t a = 0; a * kChainArenaBytes < net->chain_bytes; ++a) HIP_TRY(hipMemset(net->dev_ws + net->chain_off + a * kChainArenaBytes, 0, kChainCtrlBytes));
+    if (!net->splitk_bytes || !net->dev_ws) return YOLO_OK;
+    const size_t per = net->splitk_bytes / (size_t)net->arenas;
+    for (int a = 0; a < net->arenas; ++a)
+        HIP_TRY(hipMemset(net->dev_ws + net->splitk_off + (size_t)a * (per / 256 * 256), 0, per < kPairCounterBytes ? per : kPairCounterBytes));
     HIP_TRY(hipDeviceSynchronize());
     return YOLO_OK;
 }
@@ -160,8 +156,7 @@ int yolo_net_workspace_regions(const yolo_net *net, yolo_ws_region *out, int cap
     add("candidates", net->cand_off, sizeof(Candidate) * (size_t)net->opt.cand_capacity * mb, net->count_off - net->cand_off);
     add("candidate counters", net->count_off, sizeof(int) * mb * kCandCountStride, net->nms_off - net->count_off);
     add("nms scratch", net->nms_off, nms_scratch_bytes(net->opt.cand_capacity) * mb, net->obj_off - net->nms_off);
-    add("objectness", net->obj_off, net->obj_bytes, net->chain_off - net->obj_off);
-    if (net->chain_bytes) add("chained launches: counters + layer tables", net->chain_off, net->chain_bytes, net->chain_bytes);
+    add("objectness", net->obj_off, net->obj_bytes, net->splitk_off - net->obj_off);
     if (net->splitk_bytes) add("split-K tickets + slabs", net->splitk_off, net->splitk_bytes, net->splitk_bytes);
     return n;
 }
@@ -198,8 +193,6 @@ int yolo_net_bind_workspace(yolo_net *net, void *ws, size_t bytes) {
     net->dev_ws = static_cast<unsigned char *>(ws);
     net->cand_clean = 0;        // (whatever the new workspace holds where the candidate counters live)
     net->dev_ws_bytes = bytes;
-    net->chain_cache.clear();   // (its tables hold pointers into the old workspace)
-    net->chain_used[0] = net->chain_used[1] = 0;
     int rc = zero_pair_counters(net);
     if (rc) return rc;
     return YOLO_OK;
@@ -577,78 +570,6 @@ int branch_streams(yolo_net *net, int arena) {
     return (size_t)arena < net->branch.size() ? YOLO_OK : fail(YOLO_ERR_STATE, "branch tail: arena out of range");
 }
 
-// CHAINED LAUNCH (conv_chain.hip): do the kernels from `ki` on run as one launch at this batch?  A run of >= 2 consecutive convs of ONE map
-// size on the main path whose launches at this batch would take the 128 x 128 LDS-DMA tile (1x1) or the 128 x 256 tap tile (3x3 / 1), whole K,
-// lean epilogue -- Darknet-53's residual stages at 76 x 76 and 38 x 38 at batch 32.  The batch goes out as 8 groups of consecutive images (one
-// per XCD); the answer, the per-group launch parameters of every layer and their upload are cached per (kernel, batch, arena).
-const ChainEntry *chain_at(yolo_net *net, size_t ki, const Ptrs &P, int batch, hipStream_t s) {
-    static const bool off = getenv("YOLO_NO_CHAIN") != nullptr;         // A/B switch (same results either way)
-    if (off || !net->chain_bytes || net->opt.keep_all || net->opt.dtype != YOLO_DTYPE_F16 || batch % kChainGroups || batch / kChainGroups > kChainMaxImages ||
-        (size_t)(P.arena + 1) * kChainArenaBytes > net->chain_bytes || P.arena > 1)
-        return nullptr;
-    for (const ChainEntry &c : net->chain_cache)
-        if (c.ki == ki && c.batch == batch && c.arena == P.arena) return c.n ? &c : nullptr;
-    net->chain_cache.emplace_back();
-    ChainEntry &E = net->chain_cache.back();
-    E.ki = ki; E.batch = batch; E.arena = P.arena; E.n = 0;
-    const int imgs = batch / kChainGroups;
-    const size_t slab = net->splitk_bytes / (size_t)net->arenas / 256 * 256;
-    const size_t data_bytes = slab > kPairCounterBytes ? slab - kPairCounterBytes : 0;
-    std::vector<int> kinds;
-    static const int max_layers = getenv("YOLO_CHAIN_MAX") ? atoi(getenv("YOLO_CHAIN_MAX")) : kChainMaxLayers;      // debugging: shorter chains
-    for (size_t kj = ki; kj < net->kernels.size() && kinds.size() < (size_t)(max_layers < kChainMaxLayers ? max_layers : kChainMaxLayers); ++kj) {
-        const Kernel &k = net->kernels[kj];
-        if (k.kind != K_CONV || k.stem || k.side || k.head || k.fuse2_next || k.fuse2_prev || k.stride != 1 || k.outmode != OUT_NORMAL) break;
-        if (kj > ki && (k.out.H != net->kernels[ki].out.H || k.out.W != net->kernels[ki].out.W)) break;
-        ConvParams sp;
-        conv_shape_params(net, k, batch, sp);
-        const ConvPick pk = pick_conv(net, k, sp, k.tile, data_bytes);
-        if (pk.ks > 1 || pk.pair) break;
-        const int kind = pk.tile == 14 && k.ksize == 1 ? 0 : pk.tile == 8 && k.ksize == 3 ? 1 : -1;
-        if (kind < 0) break;
-        kinds.push_back(kind);
-    }
-    static const bool start3 = getenv("YOLO_CHAIN_START3") != nullptr;       // experiment: chains begin with a 3x3 (its tiles start in lockstep)
-    if (start3 && !kinds.empty() && kinds[0] != 1) return nullptr;
-    static const int only_w = getenv("YOLO_CHAIN_ONLY_W") ? atoi(getenv("YOLO_CHAIN_ONLY_W")) : 0;     // experiment: maps of this width only
-    if (only_w && net->kernels[ki].out.W != only_w) return nullptr;
-    const int n = (int)kinds.size();
-    bool any3 = false;
-    for (int kd : kinds) any3 = any3 || kd == 1;
-    if (n < 2 || !any3) return nullptr;
-    E.host.assign((size_t)kChainGroups * n, ChainLayer());
-    for (int g = 0; g < kChainGroups; ++g)
-        for (int j = 0; j < n; ++j) {
-            const Kernel &k = net->kernels[ki + j];
-            ConvParams p;
-            if (make_conv_params(net, k, P, imgs, p) != YOLO_OK) return nullptr;
-            const size_t i0 = (size_t)g * imgs;         // first image of the group
-            p.in = static_cast<const unsigned char *>(p.in) + i0 * (size_t)k.in.img_stride * net->esize;
-            p.out = static_cast<unsigned char *>(p.out) + i0 * (size_t)k.out.img_stride * net->esize;
-            if (p.has_res) p.res = static_cast<const unsigned char *>(p.res) + i0 * (size_t)k.in2.img_stride * net->esize;
-            if (!conv_chain_layer(E.host[(size_t)g * n + j], p, kinds[j], imgs)) return nullptr;
-        }
-    ChainParams &cp = E.cp;
-    memset(&cp, 0, sizeof cp);
-    cp.n_layers = n; cp.groups = kChainGroups;
-    int items = 0;
-    for (int j = 0; j < n; ++j) { cp.first[j] = items; items += E.host[j].tiles; }
-    cp.first[n] = items;
-    cp.n_items = items;
-    if (items >= (1 << 24)) return nullptr;            // (the kernel packs layer << 24 | tile)
-    const size_t bytes = E.host.size() * sizeof(ChainLayer);
-    size_t &used = net->chain_used[P.arena];
-    if (kChainCtrlBytes + used + bytes > kChainArenaBytes) return nullptr;
-    unsigned char *const base = net->dev_ws + net->chain_off + (size_t)P.arena * kChainArenaBytes;
-    ChainLayer *const dev = reinterpret_cast<ChainLayer *>(base + kChainCtrlBytes + used);
-    if (hipMemcpyAsync(dev, E.host.data(), bytes, hipMemcpyHostToDevice, s) != hipSuccess) return nullptr;
-    used += (bytes + 255) / 256 * 256;
-    cp.layers = dev;
-    cp.ctrl = reinterpret_cast<int *>(base);
-    E.n = n;
-    return &E;
-}
-
 int run_forward_pass(yolo_net *net, const float *in_dev, int batch, float *out_dev, hipStream_t s, hipEvent_t *ev, int img0, int arena,
                      long long *obj_rows_out) {
     Ptrs P{net, in_dev, out_dev, img0, arena};
@@ -682,13 +603,6 @@ int run_forward_pass(yolo_net *net, const float *in_dev, int batch, float *out_d
             s = s_branch;
         }
         if (ev && hipEventRecord(ev[2 * ki], s) != hipSuccess) return fail(YOLO_ERR_HIP, "hipEventRecord failed");
-        if (!ev && k.kind == K_CONV && !k.side) {       // (per-kernel events: every kernel on its own, as yolo_net_kernel_info lists them)
-            if (const ChainEntry *ce = chain_at(net, ki, P, batch, s)) {
-                if (launch_conv_chain(ce->cp, s) != hipSuccess) return fail(YOLO_ERR_HIP, "chained launch failed");
-                ki += (size_t)ce->n - 1;
-                continue;
-            }
-        }
         switch (k.kind) {
         case K_PREP: {
             PrepParams p;

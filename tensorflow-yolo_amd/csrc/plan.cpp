@@ -715,9 +715,6 @@ int plan_network(yolo_net *net, const yolo_layer_desc *layers, int n, std::strin
     net->obj_off = off;
     net->obj_bytes = net->head.n_classes > 0 ? (size_t)net->opt.max_batch * (net->out_count / (size_t)(5 + net->head.n_classes)) * 4 : 0;
     off += roundup_sz(net->obj_bytes, 4096);
-    net->chain_off = off;
-    net->chain_bytes = net->opt.dtype == YOLO_DTYPE_F16 ? kChainArenaBytes * (size_t)(net->arenas > 0 ? net->arenas : 1) : 0;
-    off += net->chain_bytes;
     // split-K slabs (float32 partial sums of the convs whose launch would leave the chip idle): last region of the workspace,
     // sized by yolo_net_create from the launches that can actually split (api.cpp: splitk_slab_bytes) -- 0 for most big-batch nets
     net->splitk_off = off;

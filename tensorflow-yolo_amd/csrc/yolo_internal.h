@@ -155,30 +155,6 @@ inline void conv_set_divisors(ConvParams &p, int stages_per_tap) {
     p.dtiles_n = make_fastdiv((uint32_t)(p.n_tiles_n > 0 ? p.n_tiles_n : 1));
 }
 
-// conv_chain.hip: consecutive convs of one stage as ONE launch (tiles of all layers from per-XCD work lists in dependency order)
-constexpr int kChainGroups = 8;             // image groups = XCDs
-constexpr int kChainMaxImages = 8;          // images per group (batch <= 64)
-constexpr int kChainMaxLayers = 24;
-constexpr int kChainCtrlStride = 32;        // ints between the queue heads (a 128-byte line each)
-constexpr int kChainExitOff = kChainGroups * kChainCtrlStride;         // ctrl[]: workgroups that have left
-constexpr int kChainTimeoutOff = kChainExitOff + 1;                    // ctrl[]: a dependency wait gave up (never expected)
-constexpr int kChainDoneOff = kChainExitOff + kChainCtrlStride;        // ctrl[]: done[group][layer][image]
-constexpr int kChainCtrlInts = kChainDoneOff + kChainGroups * kChainMaxLayers * kChainMaxImages;
-struct ChainLayer {
-    ConvParams p;               // the layer at batch = images of ONE group, pointers at the group's first image
-    int kind;                   // 0: 1x1 on the 128 x 128 LDS-DMA tile (cfg 14); 1: 3x3 on the 128 x 256 tap tile (cfg 8)
-    int tiles;                  // p.n_blocks
-    int unit, rows, img_rows;   // rows of the tile grid (pixels / padded-linear positions): per tile, total, per image
-    int need[kChainMaxImages];  // tiles touching image i = what done[..][i] reaches when the layer has finished that image
-};
-struct ChainParams {
-    const ChainLayer *layers;   // [groups][n_layers], device memory
-    int *ctrl;                  // kChainCtrlInts ints, zero before the first launch (every launch leaves them zero)
-    int n_layers, groups, n_items;          // n_items: tiles of one group's queue
-    int first[kChainMaxLayers + 1];         // first queue item of layer j (same for every group)
-    unsigned long long *trace;              // experiment build (YOLO_CHAIN_TRACE): 4 x uint64 per (group, item): claimed, dependencies met, finished (100 MHz), HW_ID
-};
-
 struct PrepParams {            // float32 NHWC [B,H,W,C] -> T NHWC [B,H,W,Cpad], zero fill
     const float *in;
     void *out;
@@ -305,10 +281,6 @@ bool dma_cfg_is_tap(int cfg);
 int dma_cfg_bkc(int cfg);
 hipError_t launch_conv_dma(const ConvParams &p, int cfg, hipStream_t s);
 hipError_t launch_conv_tap(const ConvParams &p, int variant, hipStream_t s);       // conv_tap.hip: 3x3/1 with tap reuse
-hipError_t prepare_conv_dma(ConvParams &p, int cfg);           // what launch_conv_dma adds to the caller's parameters (tile counts, grids, divisors)
-bool conv_chain_layer(ChainLayer &L, const ConvParams &p, int kind, int imgs);     // conv_chain.hip
-hipError_t launch_conv_chain(const ChainParams &cp, hipStream_t s);
-const char *conv_chain_symbol();
 bool conv_tap_stream_ok(const ConvParams &p, int variant);                         // the persistent form takes this launch
 bool conv_tap_fits(int variant, int W);
 bool conv_tap_is2d(int variant);
@@ -372,18 +344,6 @@ struct Kernel {
     std::string note;
 };
 
-// one cached answer of "do the kernels from `ki` on run as a chained launch at this batch?" (api.cpp: chain_at)
-const size_t kChainCtrlBytes = 8192;
-const size_t kChainArenaBytes = (size_t)1 << 20;
-static_assert(kChainCtrlInts * 4 <= (int)kChainCtrlBytes, "chain counters");
-struct ChainEntry {
-    size_t ki = 0;
-    int batch = 0, arena = 0;
-    int n = 0;                  // kernels the launch covers (0: no chain starts here)
-    ChainParams cp;
-    std::vector<ChainLayer> host;       // source of the table upload (alive until the net goes)
-};
-
 struct LayerInfo {
     yolo_layer_desc d;
     int H = 0, W = 0, C = 0;
@@ -407,10 +367,6 @@ struct yolo_net {
     size_t logits_off = 0, cand_off = 0, count_off = 0, nms_off = 0;   // nms_off: global NMS slabs (cand_capacity > 4096)
     size_t splitk_off = 0, splitk_bytes = 0;   // float32 partial-sum slabs of the split-K convs (small feature maps at small batch)
     size_t obj_off = 0, obj_bytes = 0;     // compact objectness logits [max_batch][rows] written by the head convs for the decode
-    // chained launches (conv_chain.hip): per arena [counters, kChainCtrlBytes | layer tables, built at the first forward of a batch size]
-    size_t chain_off = 0, chain_bytes = 0;
-    std::vector<yolo::ChainEntry> chain_cache;
-    size_t chain_used[2] = {0, 0};         // bytes of each arena's table space handed out
     bool obj_valid = false;                // ... and whether the last forward filled all of it
     int cand_clean = 0;                    // how many candidate counters, from the first, are known to be zero (the last detect's NMS returned them): no memset launch in front of a decode of at most that batch
     int side_chains = 0;                   // number of branch tails (Kernel.side ids 1..side_chains)
