@@ -240,8 +240,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, float4v (&acc
 // before the first is used, leaky ReLU as mul + max (max(s x, x) with s = 0.1 or 1: no select; the conv kernels are compiled
 // with -fno-honor-nans, so no canonicalisation), + residual in float32 (a code path of its own, no select), ONE rounding, 16-byte stores.  Same values as the generic epilogue for every finite
 // input.  The accumulators start from the bias (conv_init_acc_bias).
-// LDAUX: cache policy of the residual loads (16 = sc1 for the chained launch, conv_chain.hip: the residual may have been written in this launch).
-template <int TM, int TP, int PADQ, bool RES, bool PIL = false, int LDAUX = 0>
+template <int TM, int TP, int PADQ, bool RES, bool PIL = false>
 __device__ __forceinline__ void conv_epilogue_fast_body(const ConvParams &p, float4v (&acc)[TM][TP], int cbase, int m_wave, int fr) {
     typedef _Float16 T;
     constexpr int CH = 4 * TM, EPC = 8, NQ = CH / EPC;
@@ -262,7 +261,7 @@ __device__ __forceinline__ void conv_epilogue_fast_body(const ConvParams &p, flo
             const uint32_t ro = (uint32_t)(((long long)n * p.res_img_stride + (long long)rem * p.res_ld + cbase) * 2);
             const uint32_t roff = ok ? ro : YOLO_INVALID_OFF;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) rv[b][q] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, q * 16, LDAUX));
+            for (int q = 0; q < NQ; ++q) rv[b][q] = __builtin_bit_cast(uint4v, __builtin_amdgcn_raw_buffer_load_b128(rs_res, roff, q * 16, 0));
         }
     }
     const float slope = p.leaky ? 0.1f : 1.0f;
@@ -287,10 +286,10 @@ __device__ __forceinline__ void conv_epilogue_fast_body(const ConvParams &p, flo
     }
 }
 
-template <int TM, int TP, int PADQ, bool PIL = false, int LDAUX = 0>
+template <int TM, int TP, int PADQ, bool PIL = false>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvParams &p, float4v (&acc)[TM][TP], int cbase, int m_wave, int fr) {
-    if (p.has_res) conv_epilogue_fast_body<TM, TP, PADQ, true, PIL, LDAUX>(p, acc, cbase, m_wave, fr);
-    else conv_epilogue_fast_body<TM, TP, PADQ, false, PIL, LDAUX>(p, acc, cbase, m_wave, fr);
+    if (p.has_res) conv_epilogue_fast_body<TM, TP, PADQ, true, PIL>(p, acc, cbase, m_wave, fr);
+    else conv_epilogue_fast_body<TM, TP, PADQ, false, PIL>(p, acc, cbase, m_wave, fr);
 }
 
 // BACK-TO-BACK 1x1 (ConvParams.fuse2): the 1x1 conv that reads this conv's output (Darknet-53: the first layer of the next
