@@ -51,9 +51,6 @@
 #ifndef YOLO_TAP_LATE_FROM
 #define YOLO_TAP_LATE_FROM 4
 #endif
-#ifndef YOLO_TAP_PF         // weight fragments one tap ahead (round 5, below: PF)
-#define YOLO_TAP_PF 1
-#endif
 #ifndef YOLO_TAP_STAGGER
 #define YOLO_TAP_STAGGER 1
 #endif
@@ -156,15 +153,6 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
     // plane R mod TP at row R / TP (planes of PL rows) -- free, because the LDS-DMA takes a per-lane source offset anyway.  The epilogue's
     // lane <-> pixel map changes accordingly (conv_common.h: frag_pos).
     constexpr bool PIL = YOLO_TAP_PIL != 0 && MODE == 1 && !F32;
-    // WEIGHT FRAGMENTS ONE TAP AHEAD (PF; the position-interleaved tiles).  The start-offset probe (profiles/r05_ablation.md section 15) shows what a tap of
-    // a workgroup that has its CU to itself -- and of the OLDER of two that share one -- consists of: 512 cycles of MFMA issue per SIMD and ~420 in which
-    // nothing feeds the pipe: barrier, four weight-fragment reads, their latency.  The reads stood behind the barrier because the barrier is what
-    // certifies the tap's weights.  Here the weights of tap t + 1 are certified at barrier t (every wave waits for ITS DMA of them in front of it; they
-    // were requested three taps earlier, so the lead stays two taps), and tap t reads them during its own MFMAs into the fragment registers it has just
-    // finished with -- fragment a of tap t + 1 behind the last MFMA on fragment a of tap t: no extra registers, and the first MFMA of a tap waits for nothing.
-    // The ring stays at three slots: at barrier t the fragments of tap t are in registers (every wave drains its LDS reads in front of the barrier),
-    // so slot t mod 3 is free for the DMA of tap t + 3 right behind it.
-    constexpr bool PF = YOLO_TAP_PF != 0 && PIL;
     constexpr int PL = (PRG * 16) / TP;             // patch rows per plane
     constexpr int ROWB = 64;
     constexpr int NA = WM * TM * 16;
@@ -370,8 +358,6 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
 
     // position-interleaved fragments (PIL, above): input fragment j of kernel row kh = patch positions u + TP fr, u = kh qW + wave offset + j
     uint4v G[PIL ? TP : 1];
-    uint4v FA[PF ? TM : 1];     // PF: the weight fragments of the CURRENT tap (read during the previous one)
-    uint4v FAL;                 // ... the last of them (a variable of its own: as FA[TM - 1], refilled through a temporary, it went through scratch)
     auto g_ptr = [&](int buf, int u) {
         // (3 (TP + 2) loop-invariant addresses per patch buffer: with the in-place MFMAs the 128-register tiles have the registers to keep
         // them -- 18 at TP = 4 -- and computing them where they are used cost +35 % vector instructions, +5 % wave cycles: profiles/r05_ablation.md)
@@ -385,31 +371,7 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
     // in flight across the barrier -- behind it only the weight fragments (whose DMA the barrier publishes) are waited for.  After tap
     // kw = 0 / 1: fragment j = TP + kw into the registers of fragment j = kw (dead); after kw = 2: the TP fragments of the next kernel
     // row (next slice: the other patch buffer).  `nbuf`: the buffer the tap behind this one reads.
-    auto compute_pil = [&](int slot, int buf, int kh, int kw, int nbuf, auto &&issue_dma, bool has_next = true) {
-        if constexpr (PF) {
-            // (see PF above) this tap's weight fragments are in FA; the next tap's are read from slot + 1 as FA's registers come free
-            const unsigned char *An = smem + ((slot + 1) % S) * A_BYTES + a_frag;
-            const int u0 = kh * p.qW + wn * (TP * 16);
-            // order: the LAST fragment of the next tap first (into spare registers), the others as their registers come free, the position fragments
-            // last -- the wait in front of the next barrier then only covers weight-fragment reads that are several MFMAs old (run_slice: lgkmcnt(NG))
-            uint4v n_last = FAL;
-            if (has_next) n_last = *reinterpret_cast<const uint4v *>(An + (TM - 1) * 16 * ROWB);
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-#pragma unroll
-                for (int b = 0; b < TP; ++b) tap_mfma<T>(acc[a][b], a + 1 < TM ? FA[a] : FAL, G[(b + kw) % TP]);
-                if (a == 0) issue_dma();        // (behind the first MFMAs: the requests' issue, ~60-180 cycles each, no longer stands in front of them)
-                if (a + 1 < TM) { if (has_next) FA[a] = *reinterpret_cast<const uint4v *>(An + a * 16 * ROWB); }
-            }
-            FAL = n_last;
-            __builtin_amdgcn_sched_barrier(0);      // (the position-fragment reads stay behind every weight-fragment read)
-            if (kw < 2) G[kw % TP] = *reinterpret_cast<const uint4v *>(g_ptr(buf, u0 + TP + kw));
-            else {
-                const int un = (kh < 2 ? (kh + 1) * p.qW : 0) + wn * (TP * 16);
-#pragma unroll
-                for (int b = 0; b < TP; ++b) G[b] = *reinterpret_cast<const uint4v *>(g_ptr(nbuf, un + b));
-            }
-        } else
+    auto compute_pil = [&](int slot, int buf, int kh, int kw, int nbuf, auto &&issue_dma) {
         if constexpr (PIL) {
             const unsigned char *A = smem + slot * A_BYTES + a_frag;
             const int u0 = kh * p.qW + wn * (TP * 16);
@@ -514,7 +476,6 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
         issue_weights(2, c_begin, 1);
     } else if constexpr (W_FIRST) {
         issue_patch(c_begin, 0);        // (the weights are on their way: above)
-        if constexpr (PF) issue_weights(2, c_begin, 2);
     } else {
         issue_patch(c_begin, 0);
         issue_weights(0, c_begin, 0);
@@ -561,9 +522,7 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
         for (int tap = 0; tap < 9; ++tap) {
             // Wait for the weights of this tap.  Issue order per tap: weights(tap+2), then (tap 0 only) the next
             // patch; younger than weights(tap) are weights(tap+1) and, at taps 1 and 2, that patch.
-            // (PF: the same counts one tap further on -- in front of barrier `tap` the weights of tap + 1 must have landed, those of tap + 2 may be
-            // in flight; the last TWO taps of the K loop have nothing younger in flight)
-            const bool last = !more && (tap == 8 || (PF && !LATE && tap == 7));
+            const bool last = !more && tap == 8;
             const bool with_patch = more && (tap == 1 || tap == 2);
             if constexpr ((YOLO_TAP_DBG & 32) != 0) { if (last) tap_wait_vm<0>(); } else     // timing experiment (results wrong): no DMA waits inside the K loop
             if (last) tap_wait_vm<0>();
@@ -580,27 +539,19 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
             // arrives, so a slot is provably idle when another wave's DMA (issued after the barrier) overwrites it.
             // (The compiler otherwise sinks the last fragment reads + MFMAs below the barrier: 0.5 % faster, but safe
             // only by timing.)
-            // (PF: the fragments of THIS tap, read during the last one, are in registers before any wave's DMA may overwrite their slot)
-            // In flight may stay what the last tap read LAST: its position fragments (one, or TP at the end of a kernel row), from the patch.
-            if constexpr (PF && !LATE) {
-                // (no "memory" clobber: the barrier builtin behind it orders memory for the compiler; with one, a fragment register set was spilled to scratch)
-                if ((tap + 8) % 3 < 2) asm volatile("s_waitcnt lgkmcnt(1)");       // (`tap` is a constant once the loop is unrolled)
-                else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TP));
-            }
             __builtin_amdgcn_sched_barrier(0);
             // (timing experiments, results wrong: YOLO_TAP_DBG 8 = a barrier every third tap only, 16 = none)
             if constexpr (!((YOLO_TAP_DBG & 16) != 0 || ((YOLO_TAP_DBG & 8) != 0 && tap % 3 != 0))) __builtin_amdgcn_s_barrier();
             auto issue_dma = [&]() {
-                {   // weights two taps ahead of the tap whose fragments are read next (PF: three taps ahead of this one, into this tap's slot)
-                    constexpr int AHEAD = PF && !LATE ? 3 : 2;
-                    const int t2 = tap + AHEAD < 9 ? tap + AHEAD : tap + AHEAD - 9;
-                    const int c2 = tap + AHEAD < 9 ? c : c + 1;
-                    if (c2 < C) issue_weights(t2, c2, (tap + AHEAD) % S);
+                {   // weights two taps ahead
+                    const int t2 = tap + 2 < 9 ? tap + 2 : tap + 2 - 9;
+                    const int c2 = tap + 2 < 9 ? c : c + 1;
+                    if (c2 < C) issue_weights(t2, c2, (tap + 2) % S);
                 }
                 if (tap == 0 && more) issue_patch(c + 1, buf ^ 1);
             };
             const int kh = tap / 3, kw = tap - 3 * kh;
-            if constexpr (PIL && !LATE) compute_pil(tap % S, buf, kh, kw, tap == 8 ? buf ^ 1 : buf, issue_dma, more || tap < 8);
+            if constexpr (PIL && !LATE) compute_pil(tap % S, buf, kh, kw, tap == 8 ? buf ^ 1 : buf, issue_dma);
             else {
                 issue_dma();
                 if constexpr (LATE) compute_late(tap % S, buf, TWO_D ? kh * PW + kw : kh * p.qW + kw);
@@ -609,15 +560,8 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
         }
     };
     if constexpr (PIL) {        // the position fragments of the very first tap: the patch is the oldest DMA in flight (W_FIRST: the youngest)
-        if constexpr (PF) { if (has_a) tap_wait_vm<JA>(); else tap_wait_vm<0>(); }       // (DMA order W0, W1, patch, W2: W2 may be in flight)
-        else if (has_a && !W_FIRST) tap_wait_vm<2 * JA>(); else tap_wait_vm<0>();
+        if (has_a && !W_FIRST) tap_wait_vm<2 * JA>(); else tap_wait_vm<0>();
         __builtin_amdgcn_s_barrier();
-        if constexpr (PF) {     // the weight fragments of the first tap (in front of the position fragments: see the wait in run_slice)
-#pragma unroll
-            for (int a = 0; a + 1 < TM; ++a) FA[a] = *reinterpret_cast<const uint4v *>(smem + a_frag + a * 16 * ROWB);
-            FAL = *reinterpret_cast<const uint4v *>(smem + a_frag + (TM - 1) * 16 * ROWB);
-            __builtin_amdgcn_sched_barrier(0);
-        }
 #pragma unroll
         for (int b = 0; b < TP; ++b) G[b] = *reinterpret_cast<const uint4v *>(g_ptr(0, wn * (TP * 16) + b));
         __builtin_amdgcn_sched_barrier(0);
