@@ -186,6 +186,8 @@ __global__ void __launch_bounds__(WM * WN * 64, OCC) conv3x3_tap_kernel(const Co
 #ifdef YOLO_EXPERIMENT      // block trace (tools/trace_blocks.py); not in the product build
     const unsigned long long t_start = p.trace ? wall_clock64() : 0ull;
     const unsigned long long c_start = p.trace ? (unsigned long long)clock64() : 0ull;
+    // experiment: (dbg & 64) the workgroups with an odd threadgroup id run at wave priority 3 -- does priority decide who gets the CU?
+    if ((p.dbg & 64) && ((__builtin_amdgcn_s_getreg(0xF804) >> 16) & 1u)) __builtin_amdgcn_s_setprio(3);
     // experiment (tools/offset_probe.py): the workgroups with an odd threadgroup id on their CU start (dbg >> 8) x 0.25 us late
     if ((p.dbg >> 8) > 0 && ((__builtin_amdgcn_s_getreg(0xF804) >> 16) & 1u)) {
         const unsigned long long until = wall_clock64() + (unsigned long long)(p.dbg >> 8) * 25ull;

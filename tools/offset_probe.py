@@ -18,7 +18,7 @@ path = "/tmp/offset_trace.bin"
 for units in [0, 1, 2, 4, 8, 20, 40, 80]:
     if os.path.exists(path): os.remove(path)
     os.environ["YOLO_CONV_TRACE"] = path
-    os.environ["YOLO_CONV_DBG"] = str(units << 8)
+    os.environ["YOLO_CONV_DBG"] = str((units << 8) | int(os.environ.get("PROBE_DBG_BITS", "0")))
     eng.forward(x); torch.cuda.synchronize()
     del os.environ["YOLO_CONV_TRACE"]
     raw = np.fromfile(path, dtype=np.uint64); pos = 0; seen = set()
